@@ -1,0 +1,141 @@
+/* pinsage_hip.h -- C ABI of libpinsage_hip.so, the MI355X (gfx950) implementation of the
+ * PinSage hot path of anisanazim/Movie-Recommendation-Engine.
+ *
+ * The reference has no FFI: its boundary for this path is the Python class surface
+ * (utils/random_walk.py, model/pinsage.py, model/aggregators.py, utils/nearest_neighbors.py).
+ * Each entry point below names the reference code (file:line, relative to the reference
+ * root) whose work it replaces; the Python classes of the same names under
+ * movie-recommendation-engine_amd/{utils,model}/ bind these symbols with ctypes
+ * (see INTEGRATION.md for the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless the parameter name starts with `h_`;
+ *    buffers are caller-allocated and caller-owned; inputs are never written.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *    synchronises, nothing allocates, no global state: calls are re-entrant and
+ *    hipGraph-capturable.
+ *  - return value: PS_OK (0) or a negative PS_E* code; `ps_error_string` names it.
+ *  - node ids are int32 on the device (V < 2^31), edge offsets int64.
+ */
+#ifndef PINSAGE_HIP_H
+#define PINSAGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_OK 0
+#define PS_EINVAL (-1)      /* bad argument / unsupported shape            */
+#define PS_ELAUNCH (-2)     /* HIP launch or runtime error                 */
+#define PS_EWORKSPACE (-3)  /* workspace too small                         */
+#define PS_EUNSUPPORTED (-4)
+
+#define PS_RNG_STREAM 0     /* uniforms[] holds the numpy legacy MT19937 stream */
+#define PS_RNG_PHILOX 1     /* Philox4x32-10, counter (node, walk, step, call)  */
+
+typedef void *ps_stream_t;
+
+int ps_abi_version(void);
+const char *ps_error_string(int code);
+
+/* ---- a1: RandomWalkSampler._prepare_adjacency_list (utils/random_walk.py:33-50) -----------
+ * adj_list[src].append((dst, w)) in edge-column order  ==  CSR stably sorted by src.
+ * src/dst int64[E] (the two rows of edge_index), w float[E] or NULL (=> 1.0, :45-48).
+ * Out: rowptr int64[V+1], col int32[E], wsorted double[E] (fp32 weight widened exactly). */
+size_t ps_csr_build_workspace_bytes(int64_t E, int64_t V);
+int ps_csr_build(const int64_t *src, const int64_t *dst, const float *w, int64_t E, int64_t V,
+                 int64_t *rowptr, int32_t *col, double *wsorted,
+                 void *workspace, size_t workspace_bytes, ps_stream_t stream);
+
+/* Per-row CDF, the arithmetic `np.random.choice(dest, p=w/w.sum())` performs per step
+ * (utils/random_walk.py:76,79): p = w / numpy_sum(w); cdf = cumsum(p); cdf /= cdf[-1], fp64,
+ * same operation order (bit-exact).  cdf double[E]. */
+int ps_cdf_build(const int64_t *rowptr, const double *wsorted, int64_t V, double *cdf, ps_stream_t stream);
+
+/* flags[0] = 1 iff some edge points at a node with out-degree 0 (a reachable sink: the
+ * reference's walk then breaks early, utils/random_walk.py:68-69, and its RNG consumption
+ * becomes data dependent); flags[1] = max out-degree.  flags int64[2]. */
+int ps_graph_stats(const int64_t *rowptr, const int32_t *col, int64_t E, int64_t V, int64_t *flags,
+                   ps_stream_t stream);
+
+/* ---- a2-a4: _single_walk / sample_neighbors / batch_sample_neighbors (utils/random_walk.py:52-142)
+ * For each start node: W walks of L weighted steps (pick = searchsorted(cdf, u, 'right')),
+ * visit counts over walk[1:], top-T by (count desc, first-visit order), one wave per start node.
+ * rng_mode PS_RNG_STREAM: step (walk w, step s) of start i reads uniforms[uoff[i] + w*L + s]
+ *   (uoff int64[B]; the numpy call order on a graph without reachable sinks).
+ * rng_mode PS_RNG_PHILOX: uniforms/uoff ignored; u = philox(seed; node, w, s, call).
+ * Out: ids int32[B,T] (-1 pad), counts int32[B,T] (0 pad), nvalid int32[B].
+ * The reference's weights are counts[i,j] / sum_j counts[i,:nvalid[i]] (:113-115). */
+int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
+                   const int64_t *starts, int64_t B, int W, int L, int T,
+                   int rng_mode, const double *uniforms, const int64_t *uoff,
+                   uint64_t seed, uint32_t call,
+                   int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream);
+
+/* _single_walk (utils/random_walk.py:52-83), batched: one walk of L steps per start node, one lane
+ * per walk.  paths int32[B,L]: the visited nodes after the start (-1 once the walk hit a sink).
+ * PS_RNG_STREAM: walk i, step s reads uniforms[uoff[i] + s]; PS_RNG_PHILOX: philox(seed; node, i, s, call). */
+int ps_walk_paths(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
+                  const int64_t *starts, int64_t B, int L, int rng_mode, const double *uniforms,
+                  const int64_t *uoff, uint64_t seed, uint32_t call, int32_t *paths, ps_stream_t stream);
+
+/* Offsets into the numpy stream: uoff[i] = W*L * #{j < i : outdeg(starts[j]) > 0};
+ * total[0] = uniforms consumed by the whole batch. */
+int ps_uniform_offsets(const int64_t *rowptr, int64_t V, const int64_t *starts, int64_t B, int W, int L,
+                       int64_t *uoff, int64_t *total, ps_stream_t stream);
+
+/* numpy legacy MT19937 `random_sample(n)` on the device: state uint32[624] + pos (0..624) in,
+ * n doubles out, advanced state/pos out (what np.random.set_state needs).  Replaces the
+ * global-RNG draws of np.random.choice at utils/random_walk.py:79. */
+int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t n, double *out,
+                             uint32_t *state_out, int32_t *pos_out, ps_stream_t stream);
+
+/* ---- a5 / a9: ImportancePooling.forward (model/pinsage.py:101-150); Weighted/Mean/Importance
+ * aggregators' gather + weighted reduce (model/aggregators.py:13-91,233-287).
+ * x float[N,H]; ids/counts int32[B,T]; nvalid int32[B]; out float[B,H].
+ * Row i: keep j < nvalid[i] with 0 <= ids[i,j] <= max_idx (:123-129); w_j = fp32(count_j/total);
+ * w /= sum(w) if > 0 (:140-143); out = sum_j w_j * x[ids_j] (:146); zeros if none (:115-117,:132-134).
+ * If wts != NULL (float[B,T]) it supplies w_j directly instead of counts (list API with arbitrary
+ * weights; aggregators).  renorm = 0 skips the `w /= sum(w)` step (weights already final). */
+int ps_importance_pool(const float *x, int64_t N, int H, const int32_t *ids, const int32_t *counts,
+                       const float *wts, const int32_t *nvalid, int64_t B, int T, int64_t max_idx,
+                       int renorm, float *out, ps_stream_t stream);
+
+/* ---- a6: the dense layers of PinSage.forward (model/pinsage.py:202,235-240,248-249) ---------
+ * y[M,N] = epilogue( x[M,K] W[N,K]^T (+ x2[M,K2] W2[N,K2]^T) + b ), fp32 MFMA, k-ordered fma chain.
+ * x2/W2 eliminate torch.cat([h_self, h_neigh]) (:238): W = lin_update.weight[:, :H], W2 = [:, H:]
+ * (ldw / ldw2 = row strides of W / W2 in floats).  flags: PS_RELU, PS_L2NORM (F.normalize, eps 1e-12). */
+#define PS_RELU 1
+#define PS_L2NORM 2
+int ps_linear(const float *x, int64_t M, int K, const float *W, int ldw, const float *b, int N,
+              const float *x2, int K2, const float *W2, int ldw2, int flags, float *y, ps_stream_t stream);
+
+/* ---- a10: LSHIndex.build/search (utils/nearest_neighbors.py:28-68 -> faiss.IndexLSH) ---------
+ * codes[n, nbits/8] : bit j = ( x . A[j,:] >= 0 ), LSB-first (faiss fvec2bitvec); A float[nbits,D]. */
+int ps_lsh_encode(const float *x, int64_t N, int D, const float *A, int nbits, uint8_t *codes, ps_stream_t stream);
+
+/* Hamming k-NN over all codes: k smallest by (distance, id), ascending; id = row + id_offset.
+ * dist int32[nq,k] (INT32_MAX pad), ids int64[nq,k] (-1 pad).  cs = bytes per code (multiple of 4). */
+size_t ps_hamming_topk_workspace_bytes(int64_t nq, int64_t N, int cs, int k);
+int ps_hamming_topk(const uint8_t *qcodes, int64_t nq, const uint8_t *codes, int64_t N, int cs, int k,
+                    int64_t id_offset, int32_t *dist, int64_t *ids,
+                    void *workspace, size_t workspace_bytes, ps_stream_t stream);
+
+/* Merge P sorted candidate lists per query (multi-GPU shards: all-gathered [P, nq, k]) into the
+ * global k best by (distance, id). */
+int ps_topk_merge(const int32_t *dist_in, const int64_t *ids_in, int P, int64_t nq, int k,
+                  int32_t *dist, int64_t *ids, ps_stream_t stream);
+
+/* ---- a11: exact search (inference.py:112-118, utils/evaluation.py:106-132) --------------------
+ * sim = E[q] . E^T ; optionally sim[q] = -inf ; top-k descending.  vals float[nq,k], ids int64[nq,k]. */
+size_t ps_dot_topk_workspace_bytes(int64_t nq, int64_t N, int D, int k);
+int ps_dot_topk(const float *E, int64_t N, int D, const int64_t *qidx, int64_t nq, int k, int exclude_self,
+                float *vals, int64_t *ids, void *workspace, size_t workspace_bytes, ps_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINSAGE_HIP_H */

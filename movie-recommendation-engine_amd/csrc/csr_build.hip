@@ -1,0 +1,219 @@
+// csr_build.hip -- adjacency ingest for the random-walk sampler on gfx950.
+//
+// Replaces RandomWalkSampler._prepare_adjacency_list (reference utils/random_walk.py:33-50):
+// the python adj_list (append in edge-column order) is a CSR stably sorted by src.  The stable
+// sort of (src, edge#) pairs is rocPRIM's radix sort (one-time ingest, not a hot kernel); the
+// row pointer comes from boundary detection on the sorted keys (no atomics -> deterministic).
+//
+// ps_cdf_build evaluates, per row, exactly what np.random.choice(dest, p=w/w.sum()) computes on
+// every step of the reference (utils/random_walk.py:76,79): p = w / numpy_sum(w); cdf =
+// cumsum(p); cdf /= cdf[-1] -- fp64, the same operation order, no FMA contraction (this file is
+// compiled with -ffp-contract=off), so the result is bit-identical with numpy's.
+#include "ps_common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
+
+__global__ void prep_keys_kernel(const int64_t *src, int64_t E, uint32_t *keys, uint32_t *vals) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        keys[e] = (uint32_t)src[e];
+        vals[e] = (uint32_t)e;
+    }
+}
+
+// rowptr[v] = first sorted position whose key >= v
+__global__ void rowptr_kernel(const uint32_t *keys, int64_t E, int64_t V, int64_t *rowptr) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= E; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t prev = (p == 0) ? -1 : (int64_t)keys[p - 1];
+        const int64_t cur = (p == E) ? V : (int64_t)keys[p];
+        for (int64_t v = prev + 1; v <= cur; ++v) rowptr[v] = p;
+    }
+}
+
+__global__ void gather_kernel(const uint32_t *perm, const int64_t *dst, const float *w, int64_t E, int32_t *col,
+                              double *wsorted) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E; p += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t e = perm[p];
+        col[p] = (int32_t)dst[e];
+        wsorted[p] = w ? (double)w[e] : 1.0;   // utils/random_walk.py:45-48
+    }
+}
+
+// ---- numpy ndarray.sum() for a contiguous fp64 vector (see oracle/pinsage_oracle.py) --------
+__device__ double pairwise_leaf(const double *a, int64_t n) {   // n <= 128
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int64_t i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i + 0]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+__device__ double pairwise_block(const double *a, int64_t n) {   // n <= 8192: depth <= 7
+    int64_t off[10], len[10];
+    double left[10];
+    int phase[10];
+    int sp = 0;
+    off[0] = 0; len[0] = n; phase[0] = 0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        if (phase[sp] == 0) {
+            if (len[sp] <= 128) { ret = pairwise_leaf(a + off[sp], len[sp]); --sp; continue; }
+            int64_t n2 = len[sp] / 2; n2 -= n2 % 8;
+            phase[sp] = 1;
+            off[sp + 1] = off[sp]; len[sp + 1] = n2; phase[sp + 1] = 0; ++sp;
+        } else if (phase[sp] == 1) {
+            left[sp] = ret;
+            int64_t n2 = len[sp] / 2; n2 -= n2 % 8;
+            phase[sp] = 2;
+            off[sp + 1] = off[sp] + n2; len[sp + 1] = len[sp] - n2; phase[sp + 1] = 0; ++sp;
+        } else {
+            ret = left[sp] + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+
+__device__ double numpy_sum(const double *a, int64_t n) {
+    double res = 0.0;                          // ufunc buffer: 8192-element chunks, sequential
+    for (int64_t i = 0; i < n; i += 8192) {
+        const int64_t m = (n - i < 8192) ? (n - i) : 8192;
+        res += pairwise_block(a + i, m);
+    }
+    return res;
+}
+
+constexpr int SMALL_ROW = 32;
+
+// rows with degree <= SMALL_ROW: one lane per row
+__global__ void cdf_small_kernel(const int64_t *rowptr, const double *w, int64_t V, double *cdf) {
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lo = rowptr[v], hi = rowptr[v + 1], n = hi - lo;
+        if (n == 0 || n > SMALL_ROW) continue;
+        const double S = numpy_sum(w + lo, n);
+        double acc = 0.0;
+        for (int64_t i = lo; i < hi; ++i) {
+            const double p = w[i] / S;
+            acc = (i == lo) ? p : acc + p;
+            cdf[i] = acc;
+        }
+        const double last = acc;
+        for (int64_t i = lo; i < hi; ++i) cdf[i] = cdf[i] / last;
+    }
+}
+
+// rows with degree > SMALL_ROW: one wave per row.  The order-dependent parts (numpy sum, cumsum)
+// run redundantly on all lanes (uniform control flow, broadcast loads); the divisions are spread
+// over the lanes.
+__global__ __launch_bounds__(256) void cdf_large_kernel(const int64_t *rowptr, const double *w, int64_t V,
+                                                        double *cdf) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t v = wave; v < V; v += nwaves) {
+        const int64_t lo = rowptr[v], hi = rowptr[v + 1], n = hi - lo;
+        if (n <= SMALL_ROW) continue;
+        const double S = numpy_sum(w + lo, n);
+        for (int64_t i = lo + lane; i < hi; i += 64) cdf[i] = w[i] / S;      // p
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // cumsum: lane 0 of the wave walks the row (stores), every lane tracks acc
+        double acc = 0.0;
+        if (lane == 0) {
+            const volatile double *pc = cdf;
+            acc = pc[lo];
+            for (int64_t i = lo + 1; i < hi; ++i) { acc = acc + pc[i]; cdf[i] = acc; }
+        }
+        const double last = __shfl(acc, 0, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t i = lo + lane; i < hi; i += 64) {
+            const volatile double *pc = cdf;
+            cdf[i] = pc[i] / last;
+        }
+    }
+}
+
+int radix_bits(int64_t V) {
+    int bits = 1;
+    while (((int64_t)1 << bits) < V && bits < 32) ++bits;
+    return bits;
+}
+
+}  // namespace
+
+extern "C" size_t ps_csr_build_workspace_bytes(int64_t E, int64_t V) {
+    if (E <= 0) return ALIGN;
+    size_t temp = 0;
+    uint32_t *kn = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, temp, kn, kn, kn, kn, (size_t)E, 0u, (unsigned)radix_bits(V), (hipStream_t)0);
+    return 4 * align_up((size_t)E * sizeof(uint32_t)) + align_up(temp) + ALIGN;
+}
+
+extern "C" int ps_csr_build(const int64_t *src, const int64_t *dst, const float *w, int64_t E, int64_t V,
+                            int64_t *rowptr, int32_t *col, double *wsorted, void *workspace, size_t workspace_bytes,
+                            ps_stream_t stream) {
+    if (E < 0 || V < 0 || V >= ((int64_t)1 << 31) || E >= ((int64_t)1 << 32) || !rowptr) return PS_EINVAL;
+    hipStream_t st = ps_stream(stream);
+    if (E == 0) {
+        if (hipMemsetAsync(rowptr, 0, (size_t)(V + 1) * sizeof(int64_t), st) != hipSuccess) return PS_ELAUNCH;
+        return PS_OK;
+    }
+    if (!src || !dst || !col || !wsorted || !workspace) return PS_EINVAL;
+    const size_t seg = align_up((size_t)E * sizeof(uint32_t));
+    if (workspace_bytes < 4 * seg + ALIGN) return PS_EWORKSPACE;
+    char *base = reinterpret_cast<char *>(align_up(reinterpret_cast<size_t>(workspace)));
+    uint32_t *keys_in = reinterpret_cast<uint32_t *>(base);
+    uint32_t *keys_out = reinterpret_cast<uint32_t *>(base + seg);
+    uint32_t *vals_in = reinterpret_cast<uint32_t *>(base + 2 * seg);
+    uint32_t *vals_out = reinterpret_cast<uint32_t *>(base + 3 * seg);
+    void *temp = base + 4 * seg;
+    size_t temp_bytes = workspace_bytes - (size_t)((base + 4 * seg) - reinterpret_cast<char *>(workspace));
+    size_t need = 0;
+    const unsigned bits = (unsigned)radix_bits(V);
+    if (rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)E, 0u, bits, st) != hipSuccess)
+        return PS_ELAUNCH;
+    if (need > temp_bytes) return PS_EWORKSPACE;
+    int64_t grid = ps_cdiv(E, 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(prep_keys_kernel, dim3((unsigned)grid), dim3(256), 0, st, src, E, keys_in, vals_in);
+    PS_CHECK_LAUNCH();
+    if (rocprim::radix_sort_pairs(temp, need, keys_in, keys_out, vals_in, vals_out, (size_t)E, 0u, bits, st) != hipSuccess)
+        return PS_ELAUNCH;
+    hipLaunchKernelGGL(rowptr_kernel, dim3((unsigned)grid), dim3(256), 0, st, keys_out, E, V, rowptr);
+    PS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)grid), dim3(256), 0, st, vals_out, dst, w, E, col, wsorted);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+extern "C" int ps_cdf_build(const int64_t *rowptr, const double *wsorted, int64_t V, double *cdf, ps_stream_t stream) {
+    if (!rowptr || V < 0) return PS_EINVAL;
+    if (V == 0) return PS_OK;
+    if (!wsorted || !cdf) return PS_EINVAL;
+    hipStream_t st = ps_stream(stream);
+    int64_t g1 = ps_cdiv(V, 256);
+    if (g1 > 8192) g1 = 8192;
+    hipLaunchKernelGGL(cdf_small_kernel, dim3((unsigned)g1), dim3(256), 0, st, rowptr, wsorted, V, cdf);
+    PS_CHECK_LAUNCH();
+    int64_t g2 = ps_cdiv(V, 4);
+    if (g2 > 256 * 8) g2 = 256 * 8;
+    hipLaunchKernelGGL(cdf_large_kernel, dim3((unsigned)g2), dim3(256), 0, st, rowptr, wsorted, V, cdf);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}

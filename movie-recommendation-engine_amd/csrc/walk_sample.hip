@@ -1,0 +1,345 @@
+// walk_sample.hip -- random-walk neighbour sampling on gfx950.
+//
+// Replaces RandomWalkSampler._single_walk / sample_neighbors / batch_sample_neighbors
+// (reference utils/random_walk.py:52-142).  One 64-lane wave owns one start node:
+//   1. walk phase   : lanes = walks; each step is searchsorted(cdf[row], u, 'right') on the
+//                     fp64 per-row CDF (the arithmetic np.random.choice(p=...) performs, :76-79);
+//                     visited ids are staged in LDS in Counter-insertion order (walk-major).
+//   2. count phase  : an LDS open-addressing table keyed by node id gives every position its
+//                     visit count (ds atomics) and first-visit position (atomic min).
+//   3. select phase : classes of equal count are swept from the highest count down; inside a
+//                     class, a wave ballot + prefix popcount over positions gives the
+//                     first-visit rank, i.e. python's stable sorted(..., reverse=True)[:T] (:107).
+// No global atomics, no inter-wave communication: results do not depend on scheduling.
+#include "ps_common.h"
+
+namespace {
+
+struct WalkArgs {
+    const int64_t *rowptr;
+    const int32_t *col;
+    const double *cdf;
+    int64_t V;
+    const int64_t *starts;
+    int64_t B;
+    int W, L, T;
+    int rng_mode;
+    const double *uniforms;
+    const int64_t *uoff;
+    uint32_t seed_lo, seed_hi, call;
+    int32_t *ids;
+    int32_t *counts;
+    int32_t *nvalid;
+    int hs_log2;
+};
+
+__device__ __forceinline__ double philox_uniform(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                                                 uint32_t c2, uint32_t c3) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    // genrand_res53 combination of two 32-bit words
+    return ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BITMAP_WORDS = 40;   // counts <= 1024 -> 33 words, padded
+
+template <int NP>
+__global__ __launch_bounds__(256) void walk_sample_kernel(WalkArgs a) {
+    extern __shared__ int32_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int HS = 1 << a.hs_log2;
+    const int P = a.W * a.L;
+    const int per_wave = NP * 64 + 3 * HS + BITMAP_WORDS;
+    int32_t *posb = smem + wv * per_wave;
+    int32_t *hkey = posb + NP * 64;
+    int32_t *hcnt = hkey + HS;
+    int32_t *hfirst = hcnt + HS;
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(hfirst + HS);
+    const int nbw = (P >> 5) + 1;
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+
+    for (int64_t i = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv; i < a.B; i += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const int64_t s = uniform_i64(a.starts[i]);
+        int64_t lo0 = 0, hi0 = 0;
+        if (s >= 0 && s < a.V) {
+            lo0 = uniform_i64(a.rowptr[s]);
+            hi0 = uniform_i64(a.rowptr[s + 1]);
+        }
+        int32_t *oid = a.ids + i * a.T;
+        int32_t *ocn = a.counts + i * a.T;
+        if (hi0 == lo0) {   // isolated start node -> ([], [])  (random_walk.py:109-110)
+            for (int t = lane; t < a.T; t += 64) { oid[t] = -1; ocn[t] = 0; }
+            if (lane == 0) a.nvalid[i] = 0;
+            continue;
+        }
+        const int64_t ubase = (a.rng_mode == PS_RNG_STREAM) ? uniform_i64(a.uoff[i]) : 0;
+
+        // ---------------- walk phase --------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < NP; ++j) posb[j * 64 + lane] = -1;
+        ps_wave_lds_sync();
+        for (int w0 = 0; w0 < a.W; w0 += 64) {
+            const int w = w0 + lane;
+            const bool act = w < a.W;
+            bool alive = act;
+            int64_t cur = s;
+            for (int st = 0; st < a.L; ++st) {
+                int64_t lo = lo0, hi = hi0;
+                if (st > 0 && alive) {
+                    lo = a.rowptr[cur];
+                    hi = a.rowptr[cur + 1];
+                }
+                if (hi == lo) alive = false;          // sink: the walk stops (random_walk.py:68-69)
+                int32_t nxt = -1;
+                if (alive) {
+                    double u;
+                    if (a.rng_mode == PS_RNG_STREAM) u = a.uniforms[ubase + (int64_t)w * a.L + st];
+                    else u = philox_uniform(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)w, (uint32_t)st, a.call);
+                    int64_t l = lo, h = hi;
+                    while (l < h) {                   // searchsorted(cdf, u, side='right')
+                        const int64_t mid = l + ((h - l) >> 1);
+                        if (a.cdf[mid] <= u) l = mid + 1; else h = mid;
+                    }
+                    if (l >= hi) l = hi - 1;          // cdf[-1] == 1.0 > u; defensive only
+                    nxt = a.col[l];
+                    cur = nxt;
+                }
+                if (act) posb[w * a.L + st] = nxt;
+            }
+        }
+        // ---------------- count phase -------------------------------------------------
+        for (int h = lane; h < HS; h += 64) { hkey[h] = -1; hcnt[h] = 0; hfirst[h] = 0x7fffffff; }
+        for (int b = lane; b < nbw; b += 64) bitmap[b] = 0u;
+        ps_wave_lds_sync();
+        int32_t vid[NP], slot[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int p = j * 64 + lane;
+            vid[j] = posb[p];
+            slot[j] = -1;
+            if (vid[j] >= 0) {
+                uint32_t h = ((uint32_t)vid[j] * 2654435761u) >> (32 - a.hs_log2);
+                while (true) {
+                    const int old = atomicCAS(&hkey[h], -1, vid[j]);
+                    if (old == -1 || old == vid[j]) break;
+                    h = (h + 1) & (uint32_t)(HS - 1);
+                }
+                atomicAdd(&hcnt[h], 1);
+                atomicMin(&hfirst[h], p);
+                slot[j] = (int32_t)h;
+            }
+        }
+        ps_wave_lds_sync();
+        int32_t cr[NP];   // visit count if this position is the first visit of its node, else 0
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            cr[j] = 0;
+            if (slot[j] >= 0 && hfirst[slot[j]] == j * 64 + lane) {
+                cr[j] = hcnt[slot[j]];
+                atomicOr(&bitmap[cr[j] >> 5], 1u << (cr[j] & 31));
+            }
+        }
+        ps_wave_lds_sync();
+        // ---------------- select phase ------------------------------------------------
+        int emitted = 0;
+        for (int wd = nbw - 1; wd >= 0 && emitted < a.T; --wd) {
+            uint32_t bits = __builtin_amdgcn_readfirstlane(bitmap[wd]);
+            while (bits != 0u && emitted < a.T) {
+                const int b = 31 - __builtin_clz(bits);
+                bits &= ~(1u << b);
+                const int c = wd * 32 + b;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const bool flag = cr[j] == c;
+                    const uint64_t mask = __ballot(flag);
+                    if (flag) {
+                        const int r = emitted + __popcll(mask & lanemask_lt);
+                        if (r < a.T) { oid[r] = vid[j]; ocn[r] = c; }
+                    }
+                    emitted += __popcll(mask);
+                }
+            }
+        }
+        const int nv = emitted < a.T ? emitted : a.T;
+        for (int t = nv + lane; t < a.T; t += 64) { oid[t] = -1; ocn[t] = 0; }
+        if (lane == 0) a.nvalid[i] = nv;
+        ps_wave_lds_sync();
+    }
+}
+
+__global__ void walk_paths_kernel(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
+                                  const int64_t *starts, int64_t B, int L, int rng_mode, const double *uniforms,
+                                  const int64_t *uoff, uint32_t k0, uint32_t k1, uint32_t call, int32_t *paths) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = starts[i];
+        int64_t cur = s;
+        bool alive = s >= 0 && s < V;
+        const int64_t ubase = (rng_mode == PS_RNG_STREAM) ? uoff[i] : 0;
+        for (int st = 0; st < L; ++st) {
+            int32_t nxt = -1;
+            if (alive) {
+                const int64_t lo = rowptr[cur], hi = rowptr[cur + 1];
+                if (hi == lo) {
+                    alive = false;
+                } else {
+                    double u;
+                    if (rng_mode == PS_RNG_STREAM) u = uniforms[ubase + st];
+                    else u = philox_uniform(k0, k1, (uint32_t)s, (uint32_t)i, (uint32_t)st, call);
+                    int64_t l = lo, h = hi;
+                    while (l < h) {
+                        const int64_t mid = l + ((h - l) >> 1);
+                        if (cdf[mid] <= u) l = mid + 1; else h = mid;
+                    }
+                    if (l >= hi) l = hi - 1;
+                    nxt = col[l];
+                    cur = nxt;
+                }
+            }
+            paths[i * L + st] = nxt;
+        }
+    }
+}
+
+// uoff[i] = W*L * #{j < i : outdeg(starts[j]) > 0}; one block, carried chunk scan.
+__global__ __launch_bounds__(1024) void uniform_offsets_kernel(const int64_t *rowptr, int64_t V, const int64_t *starts,
+                                                               int64_t B, int64_t WL, int64_t *uoff, int64_t *total) {
+    __shared__ int wsum[16];
+    __shared__ int64_t carry;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < B; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        int act = 0;
+        if (i < B) {
+            const int64_t s = starts[i];
+            act = (s >= 0 && s < V && rowptr[s + 1] > rowptr[s]) ? 1 : 0;
+        }
+        const uint64_t m = __ballot(act);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) { if (k < wv) woff += wsum[k]; tot += wsum[k]; }
+        const int64_t c = carry;
+        if (i < B) uoff[i] = (c + woff + before) * WL;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry * WL;
+}
+
+__global__ void graph_stats_kernel(const int64_t *rowptr, const int32_t *col, int64_t E, int64_t V,
+                                   unsigned long long *flags) {
+    int64_t maxdeg = 0;
+    int sink = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t d = col[e];
+        if (rowptr[d + 1] == rowptr[d]) sink = 1;
+    }
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = rowptr[v + 1] - rowptr[v];
+        maxdeg = d > maxdeg ? d : maxdeg;
+    }
+    if (__any(sink) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1ull);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t other = __shfl_xor(maxdeg, o, 64);
+        maxdeg = other > maxdeg ? other : maxdeg;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&flags[1], (unsigned long long)maxdeg);
+}
+
+}  // namespace
+
+extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
+                              const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
+                              const double *uniforms, const int64_t *uoff, uint64_t seed, uint32_t call,
+                              int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream) {
+    if (B < 0 || W <= 0 || L <= 0 || T <= 0 || V < 0) return PS_EINVAL;
+    if (B == 0) return PS_OK;
+    if (!rowptr || !col || !cdf || !starts || !ids || !counts || !nvalid) return PS_EINVAL;
+    if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX) return PS_EINVAL;
+    if (rng_mode == PS_RNG_STREAM && (!uniforms || !uoff)) return PS_EINVAL;
+    const int64_t P = (int64_t)W * L;
+    if (P > 1024) return PS_EUNSUPPORTED;
+    if (B == 0) return PS_OK;
+    int np = 1;
+    while (np * 64 < P) np <<= 1;
+    int hs_log2 = 6;
+    while ((1 << hs_log2) < 2 * P) ++hs_log2;
+    WalkArgs a{rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff,
+               (uint32_t)seed, (uint32_t)(seed >> 32), call, ids, counts, nvalid, hs_log2};
+    const size_t lds = (size_t)WAVES_PER_BLOCK * (np * 64 + 3 * (1 << hs_log2) + BITMAP_WORDS) * sizeof(int32_t);
+    int64_t grid = ps_cdiv(B, WAVES_PER_BLOCK);
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipStream_t st = ps_stream(stream);
+    switch (np) {
+        case 1: hipLaunchKernelGGL(walk_sample_kernel<1>, dim3((unsigned)grid), dim3(256), lds, st, a); break;
+        case 2: hipLaunchKernelGGL(walk_sample_kernel<2>, dim3((unsigned)grid), dim3(256), lds, st, a); break;
+        case 4: hipLaunchKernelGGL(walk_sample_kernel<4>, dim3((unsigned)grid), dim3(256), lds, st, a); break;
+        case 8: hipLaunchKernelGGL(walk_sample_kernel<8>, dim3((unsigned)grid), dim3(256), lds, st, a); break;
+        case 16: hipLaunchKernelGGL(walk_sample_kernel<16>, dim3((unsigned)grid), dim3(256), lds, st, a); break;
+        default: return PS_EUNSUPPORTED;
+    }
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+extern "C" int ps_walk_paths(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
+                             const int64_t *starts, int64_t B, int L, int rng_mode, const double *uniforms,
+                             const int64_t *uoff, uint64_t seed, uint32_t call, int32_t *paths, ps_stream_t stream) {
+    if (B < 0 || L <= 0) return PS_EINVAL;
+    if (B == 0) return PS_OK;
+    if (!rowptr || !col || !cdf || !starts || !paths) return PS_EINVAL;
+    if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX) return PS_EINVAL;
+    if (rng_mode == PS_RNG_STREAM && (!uniforms || !uoff)) return PS_EINVAL;
+    int64_t grid = ps_cdiv(B, 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(walk_paths_kernel, dim3((unsigned)grid), dim3(256), 0, ps_stream(stream), rowptr, col, cdf, V,
+                       starts, B, L, rng_mode, uniforms, uoff, (uint32_t)seed, (uint32_t)(seed >> 32), call, paths);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+extern "C" int ps_uniform_offsets(const int64_t *rowptr, int64_t V, const int64_t *starts, int64_t B, int W, int L,
+                                  int64_t *uoff, int64_t *total, ps_stream_t stream) {
+    if (!total || B < 0 || W <= 0 || L <= 0) return PS_EINVAL;
+    if (B > 0 && (!rowptr || !starts || !uoff)) return PS_EINVAL;
+    hipLaunchKernelGGL(uniform_offsets_kernel, dim3(1), dim3(1024), 0, ps_stream(stream), rowptr, V, starts, B,
+                       (int64_t)W * L, uoff, total);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+extern "C" int ps_graph_stats(const int64_t *rowptr, const int32_t *col, int64_t E, int64_t V, int64_t *flags,
+                              ps_stream_t stream) {
+    if (!rowptr || !flags || (E > 0 && !col)) return PS_EINVAL;
+    hipStream_t st = ps_stream(stream);
+    if (hipMemsetAsync(flags, 0, 2 * sizeof(int64_t), st) != hipSuccess) return PS_ELAUNCH;
+    int64_t n = E > V ? E : V;
+    int64_t grid = ps_cdiv(n > 0 ? n : 1, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(graph_stats_kernel, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, E, V,
+                       reinterpret_cast<unsigned long long *>(flags));
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}

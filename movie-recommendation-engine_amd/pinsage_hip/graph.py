@@ -1,0 +1,61 @@
+"""DeviceGraph: the sampler's adjacency as CSR + per-row fp64 CDF resident in HBM.
+
+Replaces RandomWalkSampler._prepare_adjacency_list (reference utils/random_walk.py:33-50) and
+the per-step `weights / weights.sum()` + `np.random.choice` CDF (:72-79)."""
+from __future__ import annotations
+
+import torch
+
+from . import native as nv
+
+
+class DeviceGraph:
+    def __init__(self, edge_index, edge_weights=None, device=None):
+        dev = nv.require_gpu() if device is None else torch.device(device)
+        ei = torch.as_tensor(edge_index)
+        if ei.dim() != 2 or ei.size(0) != 2:
+            raise ValueError("edge_index must have shape [2, num_edges]")
+        E = int(ei.size(1))
+        ei = ei.to(device=dev, dtype=torch.int64)
+        src = ei[0].contiguous()
+        dst = ei[1].contiguous()
+        if E:
+            mx = int(ei.max().item())          # reference: max_node_idx = edge_index.max().item() + 1
+            if int(ei.min().item()) < 0:
+                raise ValueError("negative node index in edge_index")
+        else:
+            mx = -1
+        V = mx + 1
+        if V >= 2 ** 31 or E >= 2 ** 32:
+            raise ValueError("graph too large for int32 node ids / uint32 edge ids")
+        w = None
+        if edge_weights is not None:
+            w = torch.as_tensor(edge_weights).to(device=dev, dtype=torch.float32).contiguous()
+            if w.numel() != E:
+                raise ValueError("edge_weights must have one entry per edge")
+        self.device = dev
+        self.V, self.E = V, E
+        self.rowptr = torch.empty(V + 1, dtype=torch.int64, device=dev)
+        self.col = torch.empty(E, dtype=torch.int32, device=dev)
+        self.cdf = torch.empty(E, dtype=torch.float64, device=dev)
+        wsorted = torch.empty(E, dtype=torch.float64, device=dev)
+        L = nv.lib()
+        ws_bytes = int(L.ps_csr_build_workspace_bytes(nv.i64(E), nv.i64(V)))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            nv.check(L.ps_csr_build(nv.ptr(src), nv.ptr(dst), nv.ptr(w), nv.i64(E), nv.i64(V), nv.ptr(self.rowptr),
+                                    nv.ptr(self.col), nv.ptr(wsorted), nv.ptr(ws), nv.C.c_size_t(ws_bytes), nv.stream()),
+                     "ps_csr_build")
+            nv.check(L.ps_cdf_build(nv.ptr(self.rowptr), nv.ptr(wsorted), nv.i64(V), nv.ptr(self.cdf), nv.stream()),
+                     "ps_cdf_build")
+            flags = torch.zeros(2, dtype=torch.int64, device=dev)
+            nv.check(L.ps_graph_stats(nv.ptr(self.rowptr), nv.ptr(self.col), nv.i64(E), nv.i64(V), nv.ptr(flags),
+                                      nv.stream()), "ps_graph_stats")
+            f = flags.tolist()
+        self.has_reachable_sink = bool(f[0])
+        self.max_degree = int(f[1])
+        self.wsorted = wsorted
+        del ws
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.cdf))

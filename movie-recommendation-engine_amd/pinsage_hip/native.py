@@ -1,0 +1,88 @@
+"""ctypes binding of libpinsage_hip.so (C ABI: include/pinsage_hip.h).
+
+There is NO fallback: if the shared library is missing every op raises LibraryMissing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libpinsage_hip.so")
+_lib = None
+
+PS_RNG_STREAM = 0
+PS_RNG_PHILOX = 1
+PS_RELU = 1
+PS_L2NORM = 2
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+# every exported symbol of include/pinsage_hip.h (checked by tests/test_abi.py)
+SYMBOLS = [
+    "ps_abi_version", "ps_error_string", "ps_csr_build_workspace_bytes", "ps_csr_build", "ps_cdf_build",
+    "ps_graph_stats", "ps_walk_sample", "ps_walk_paths", "ps_uniform_offsets", "ps_mt19937_random_sample",
+    "ps_importance_pool", "ps_linear", "ps_lsh_encode", "ps_hamming_topk_workspace_bytes", "ps_hamming_topk",
+    "ps_topk_merge", "ps_dot_topk_workspace_bytes", "ps_dot_topk",
+]
+
+
+def have_lib() -> bool:
+    return os.path.exists(SO_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not have_lib():
+            raise LibraryMissing(
+                f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the PinSage hot path.")
+        _lib = C.CDLL(SO_PATH)
+        _lib.ps_error_string.restype = C.c_char_p
+        for name in ("ps_csr_build_workspace_bytes", "ps_hamming_topk_workspace_bytes", "ps_dot_topk_workspace_bytes"):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = C.c_size_t
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise NativeError(f"{what}: {lib().ps_error_string(rc).decode()} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise NativeError("libpinsage_hip takes device (HBM) pointers; got a CPU tensor")
+    if not t.is_contiguous():
+        raise NativeError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise NativeError("the PinSage hot path needs an MI355X (torch.cuda is not available); "
+                          "there is no CPU fallback")
+    lib()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+i64 = C.c_int64
+i32 = C.c_int
+u64 = C.c_uint64
+u32 = C.c_uint32

@@ -1,0 +1,193 @@
+"""Tensor-native sampling ops over a DeviceGraph (the kernels behind RandomWalkSampler).
+
+`NeighborBatch` is the device-resident result ([B,T] ids / visit counts, [B] nvalid);
+`LazyNeighborList` is the python list-of-lists view the reference API returns
+(utils/random_walk.py:119-142), materialised only when python code actually looks at it."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import native as nv
+
+
+class NeighborBatch:
+    """ids int32[B,T] (-1 pad), counts int32[B,T] (0 pad), nvalid int32[B] on the device."""
+
+    def __init__(self, ids, counts, nvalid):
+        self.ids, self.counts, self.nvalid = ids, counts, nvalid
+        self._host = None
+
+    @property
+    def B(self):
+        return int(self.ids.size(0))
+
+    @property
+    def T(self):
+        return int(self.ids.size(1))
+
+    def host(self):
+        """(ids int64, counts int32, nvalid int32, weights fp64) as numpy; weights = count / sum(top
+        counts) in fp64 exactly like python's int/int (utils/random_walk.py:113-115)."""
+        if self._host is None:
+            ids = self.ids.cpu().numpy().astype(np.int64)
+            counts = self.counts.cpu().numpy()
+            nvalid = self.nvalid.cpu().numpy()
+            tot = counts.sum(axis=1, dtype=np.int64)
+            w = counts.astype(np.float64) / np.maximum(tot, 1)[:, None].astype(np.float64)
+            self._host = (ids, counts, nvalid, w)
+        return self._host
+
+    def to_lists(self):
+        ids, counts, nvalid, w = self.host()
+        nb = [list(ids[i, :nvalid[i]]) for i in range(ids.shape[0])]          # np.int64 scalars
+        wt = [w[i, :nvalid[i]].tolist() for i in range(ids.shape[0])]          # python floats
+        return nb, wt
+
+
+class LazyNeighborList(list):
+    """A real `list` (isinstance checks in the reference pass) whose items are produced from the
+    device batch on first python-level access.  Our own kernels read `.batch` and never touch it."""
+
+    def __init__(self, batch: NeighborBatch, kind: str):
+        super().__init__()
+        self.batch = batch
+        self.kind = kind
+        self._done = False
+
+    def _fill(self):
+        if not self._done:
+            self._done = True
+            nb, wt = self.batch.to_lists()
+            super().extend(nb if self.kind == "ids" else wt)
+
+    def __len__(self):
+        return self.batch.B
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __getitem__(self, i):
+        self._fill()
+        return super().__getitem__(i)
+
+    def __eq__(self, other):
+        self._fill()
+        return super().__eq__(other)
+
+    def __repr__(self):
+        self._fill()
+        return super().__repr__()
+
+    def __bool__(self):
+        return self.batch.B > 0
+
+    def __reduce__(self):
+        self._fill()
+        return (list, (list(super().__iter__()),))
+
+
+def _nodes_tensor(nodes, device):
+    if isinstance(nodes, torch.Tensor):
+        t = nodes.to(device=device, dtype=torch.int64)
+    else:
+        t = torch.as_tensor(np.asarray(nodes, dtype=np.int64), device=device)
+    return t.reshape(-1).contiguous()
+
+
+def draw_numpy_uniforms(n, device):
+    """n doubles of the process-global legacy numpy stream, exactly what n sequential
+    `np.random.choice(..., p=...)` calls consume (utils/random_walk.py:79), staged to HBM."""
+    u = np.random.random_sample(int(n))
+    t = torch.from_numpy(u)
+    if n:
+        t = t.pin_memory()
+    return t.to(device, non_blocking=True)
+
+
+def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None):
+    """batch_sample_neighbors on the device.  rng='numpy': the global numpy stream (bit-exact with
+    the reference; needs a graph without reachable sinks); rng='philox': counter-based.
+    `uniforms` (device fp64) overrides the numpy draw (tests / multi-GPU shards)."""
+    dev = graph.device
+    starts = _nodes_tensor(nodes, dev)
+    B = int(starts.numel())
+    if B and (int(starts.min()) < 0 or int(starts.max()) >= graph.V):
+        raise IndexError("list index out of range")      # reference: adj_list[node] (utils/random_walk.py:66)
+    ids = torch.empty((B, T), dtype=torch.int32, device=dev)
+    counts = torch.empty((B, T), dtype=torch.int32, device=dev)
+    nvalid = torch.empty(B, dtype=torch.int32, device=dev)
+    L_ = nv.lib()
+    with torch.cuda.device(dev):
+        if rng == "numpy":
+            if graph.has_reachable_sink:
+                raise NotImplementedError(
+                    "rng='numpy' needs a graph in which every edge points at a node with out-edges (true for "
+                    "the reference's bidirectional graph builders); on graphs with reachable sinks the "
+                    "reference's RNG consumption is data dependent -- use rng='philox'")
+            uoff = torch.empty(B, dtype=torch.int64, device=dev)
+            total = torch.empty(1, dtype=torch.int64, device=dev)
+            nv.check(L_.ps_uniform_offsets(nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(starts), nv.i64(B),
+                                           nv.i32(W), nv.i32(L), nv.ptr(uoff), nv.ptr(total), nv.stream()),
+                     "ps_uniform_offsets")
+            if uniforms is None:
+                n = int(total.item())
+                uniforms = draw_numpy_uniforms(n, dev)
+            mode = nv.PS_RNG_STREAM
+        elif rng == "philox":
+            uoff, uniforms, mode = None, None, nv.PS_RNG_PHILOX
+        else:
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        nv.check(L_.ps_walk_sample(nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
+                                   nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T), nv.i32(mode),
+                                   nv.ptr(uniforms), nv.ptr(uoff), nv.u64(seed & (2 ** 64 - 1)), nv.u32(call),
+                                   nv.ptr(ids), nv.ptr(counts), nv.ptr(nvalid), nv.stream()), "ps_walk_sample")
+    return NeighborBatch(ids, counts, nvalid)
+
+
+def walk_paths(graph, starts, L, rng="numpy", seed=0, call=0):
+    """One walk per start node: int32[B,L] visited nodes (-1 after a sink)."""
+    dev = graph.device
+    st = _nodes_tensor(starts, dev)
+    B = int(st.numel())
+    if B and (int(st.min()) < 0 or int(st.max()) >= graph.V):
+        raise IndexError("list index out of range")
+    paths = torch.empty((B, L), dtype=torch.int32, device=dev)
+    L_ = nv.lib()
+    with torch.cuda.device(dev):
+        if rng == "numpy":
+            if graph.has_reachable_sink:
+                raise NotImplementedError("rng='numpy' needs a graph without reachable sinks; use rng='philox'")
+            uoff = torch.empty(B, dtype=torch.int64, device=dev)
+            total = torch.empty(1, dtype=torch.int64, device=dev)
+            nv.check(L_.ps_uniform_offsets(nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(st), nv.i64(B), nv.i32(1),
+                                           nv.i32(L), nv.ptr(uoff), nv.ptr(total), nv.stream()), "ps_uniform_offsets")
+            uniforms = draw_numpy_uniforms(int(total.item()), dev)
+            mode = nv.PS_RNG_STREAM
+        else:
+            uoff, uniforms, mode = None, None, nv.PS_RNG_PHILOX
+        nv.check(L_.ps_walk_paths(nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
+                                  nv.ptr(st), nv.i64(B), nv.i32(L), nv.i32(mode), nv.ptr(uniforms), nv.ptr(uoff),
+                                  nv.u64(seed & (2 ** 64 - 1)), nv.u32(call), nv.ptr(paths), nv.stream()), "ps_walk_paths")
+    return paths
+
+
+def importance_pool(x, batch: NeighborBatch = None, ids=None, counts=None, wts=None, nvalid=None, max_idx=None,
+                    renorm=True):
+    """out[B,H] = sum_j w_j x[ids_j]  (ImportancePooling.forward, model/pinsage.py:101-150)."""
+    if batch is not None:
+        ids, counts, nvalid = batch.ids, batch.counts, batch.nvalid
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        raise TypeError("importance_pool expects fp32 features")
+    B, T = int(ids.size(0)), int(ids.size(1))
+    N, H = int(x.size(0)), int(x.size(1))
+    out = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    if max_idx is None:
+        max_idx = N - 1
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib().ps_importance_pool(nv.ptr(x), nv.i64(N), nv.i32(H), nv.ptr(ids), nv.ptr(counts), nv.ptr(wts),
+                                             nv.ptr(nvalid), nv.i64(B), nv.i32(T), nv.i64(max_idx), nv.i32(int(renorm)),
+                                             nv.ptr(out), nv.stream()), "ps_importance_pool")
+    return out

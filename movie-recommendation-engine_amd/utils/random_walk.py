@@ -1,0 +1,126 @@
+"""utils.random_walk -- drop-in for the reference module of the same name
+(reference utils/random_walk.py), backed by the gfx950 kernels of libpinsage_hip.so.
+
+Same constructor, attributes and methods as the reference's RandomWalkSampler; the python
+per-node loops are replaced by one kernel launch per batch:
+  _prepare_adjacency_list (:33-50)      -> ps_csr_build + ps_cdf_build (CSR + fp64 CDF in HBM)
+  _single_walk (:52-83)                 -> ps_walk_paths
+  sample_neighbors / batch_sample_neighbors (:85-142) -> ps_walk_sample
+With rng='numpy' (default) the sampler consumes the process-global `np.random` stream exactly
+like the reference (same ids, same fp64 weights, same RNG state afterwards).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from pinsage_hip.graph import DeviceGraph
+from pinsage_hip import sampling
+
+
+class RandomWalkSampler:
+    def __init__(self, edge_index, edge_weights=None, walk_length=2, num_walks=100, p=1.0, q=1.0,
+                 *, device=None, rng="numpy", seed=0):
+        self.edge_index = edge_index
+        self.edge_weights = edge_weights
+        self.walk_length = walk_length
+        self.num_walks = num_walks
+        self.p = p
+        self.q = q
+        self.rng = rng
+        self.seed = int(seed)
+        self._calls = 0
+        self._adj_list = None
+        self._prepare_adjacency_list(device)
+
+    def _prepare_adjacency_list(self, device=None):
+        self.graph = DeviceGraph(self.edge_index, self.edge_weights, device=device)
+
+    @property
+    def adj_list(self):
+        """The reference's python adjacency list (utils/random_walk.py:39-50), built on demand."""
+        if self._adj_list is None:
+            g = self.graph
+            rowptr = g.rowptr.cpu().numpy()
+            col = g.col.cpu().numpy()
+            w = g.wsorted.cpu().numpy()
+            self._adj_list = [list(zip(col[rowptr[v]:rowptr[v + 1]].tolist(), w[rowptr[v]:rowptr[v + 1]].tolist()))
+                              for v in range(g.V)]
+        return self._adj_list
+
+    # ---- tensor-native API (what model.pinsage uses) -------------------------------------
+    def sample_batch(self, nodes, num_neighbors=10, uniforms=None):
+        """-> sampling.NeighborBatch on the device (ids / visit counts / nvalid)."""
+        call = self._calls
+        self._calls += 1
+        return sampling.walk_sample(self.graph, nodes, int(num_neighbors), W=self.num_walks, L=self.walk_length,
+                                    rng=self.rng, seed=self.seed, call=call, uniforms=uniforms)
+
+    def single_walks(self, start_nodes):
+        """Batched _single_walk: int32[B, walk_length] device tensor (-1 after a sink)."""
+        call = self._calls
+        self._calls += 1
+        return sampling.walk_paths(self.graph, start_nodes, self.walk_length, rng=self.rng, seed=self.seed, call=call)
+
+    # ---- reference API -------------------------------------------------------------------
+    def _single_walk(self, start_node):
+        path = self.single_walks([int(start_node)])[0].tolist()
+        walk = [start_node]
+        for n in path:
+            if n < 0:
+                break
+            walk.append(np.int64(n))
+        return walk
+
+    def sample_neighbors(self, node_idx, num_neighbors=10):
+        nb, wt = self.sample_batch([int(node_idx)], num_neighbors).to_lists()
+        return nb[0], wt[0]
+
+    def batch_sample_neighbors(self, nodes, num_neighbors=10):
+        if isinstance(nodes, torch.Tensor):
+            nodes = nodes.tolist()
+        batch = self.sample_batch(nodes, num_neighbors)
+        return sampling.LazyNeighborList(batch, "ids"), sampling.LazyNeighborList(batch, "weights")
+
+    # ---- PPR helpers: on the reference's class surface but called by nothing;
+    # kept as host python over the lazily built adjacency list, same arithmetic (:144-229).
+    def compute_ppr_matrix(self, nodes, alpha=0.15, num_iterations=10):
+        if isinstance(nodes, torch.Tensor):
+            nodes = nodes.tolist()
+        n = max(self.graph.V, max(nodes) + 1)
+        out = {}
+        adj = self.adj_list
+        for source in nodes:
+            ppr = np.zeros(n)
+            ppr[source] = 1.0
+            residual = np.zeros(n)
+            residual[source] = 1.0
+            for _ in range(num_iterations):
+                for node, res in enumerate(residual):
+                    if res > 0:
+                        ppr[node] += alpha * res
+                        nbrs = adj[node] if node < len(adj) else []
+                        if nbrs:
+                            push = (1 - alpha) * res
+                            tot = sum(w for _, w in nbrs)
+                            for nb, w in nbrs:
+                                residual[nb] += push * (w / tot)
+                        residual[node] = 0
+            for target, score in enumerate(ppr):
+                if score > 0:
+                    out[(source, target)] = score
+        return out
+
+    def precompute_top_neighbors(self, nodes, num_neighbors=10):
+        ppr = self.compute_ppr_matrix(nodes)
+        top = {}
+        for source in nodes:
+            scores = [(t, s) for (src, t), s in ppr.items() if src == source]
+            scores.sort(key=lambda x: x[1], reverse=True)
+            nb = [t for t, _ in scores[:num_neighbors]]
+            wt = [s for _, s in scores[:num_neighbors]]
+            if wt:
+                tot = sum(wt)
+                wt = [w / tot for w in wt]
+            top[source] = (nb, wt)
+        return top

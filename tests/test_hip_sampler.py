@@ -1,0 +1,155 @@
+"""GPU parity of the random-walk sampler: HIP kernels (through the C ABI / the reference-shaped
+RandomWalkSampler class) against the golden vectors of the reference and the C oracle.
+Bit-exact: CSR, fp64 CDF, neighbour ids, visit counts, fp64 weights, numpy RNG position."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bipartite_graph
+
+pytestmark = pytest.mark.gpu
+
+G1 = {"A": 3, "B": 1, "C": 2, "D": 1, "E": 1}
+
+
+def _sampler(g, name, W, L, **kw):
+    from utils.random_walk import RandomWalkSampler
+    ei = torch.from_numpy(g[f"{name}_edge_index"])
+    ew = torch.from_numpy(g[f"{name}_edge_weights"]) if f"{name}_edge_weights" in g.files else None
+    return RandomWalkSampler(ei, ew, walk_length=L, num_walks=W, **kw)
+
+
+@pytest.mark.parametrize("name", sorted(G1))
+def test_golden_batch_sample_neighbors(golden, name):
+    g = golden
+    np.random.seed(int(g[f"g1_{name}_npseed"]))
+    for ci in range(G1[name]):
+        pre = f"g1_{name}_{ci}_"
+        W, L, T = [int(v) for v in g[pre + "WLT"]]
+        s = _sampler(g, f"g1_{name}", W, L)
+        nodes = g[pre + "nodes"]
+        nodes = torch.from_numpy(nodes) if name == "E" else nodes.tolist()
+        nb, wt = s.batch_sample_neighbors(nodes, T)
+        assert isinstance(nb, list) and isinstance(wt, list) and len(nb) == len(nodes)
+        ref_ids, ref_w, ref_nv = g[pre + "ids"], g[pre + "weights"], g[pre + "nvalid"]
+        for i in range(len(nodes)):
+            k = int(ref_nv[i])
+            assert [int(v) for v in nb[i]] == ref_ids[i, :k].tolist()
+            assert all(isinstance(v, np.integer) for v in nb[i])
+            assert wt[i] == ref_w[i, :k].tolist()                         # fp64 bit-exact
+    assert np.random.random_sample() == float(g[f"g1_{name}_tail"])      # global RNG advanced identically
+
+
+def test_golden_single_walk(golden):
+    g = golden
+    s = _sampler(g, "g6", 3, 4)
+    np.random.seed(11)
+    for st, ref in zip(g["g6_starts"], g["g6_walks"]):
+        assert [int(v) for v in s._single_walk(int(st))] == ref.tolist()
+
+
+def test_sink_graph_numpy_mode_refuses_and_philox_matches_oracle(golden):
+    from oracle import c_oracle as co
+    g = golden
+    s = _sampler(g, "g1_S", 20, 3)
+    assert s.graph.has_reachable_sink
+    with pytest.raises(NotImplementedError):
+        s.batch_sample_neighbors([0, 1, 2], 4)
+    s = _sampler(g, "g1_S", 20, 3, rng="philox", seed=99)
+    b = s.sample_batch([0, 1, 2, 3, 4], 4)
+    cg = co.Graph(g["g1_S_edge_index"], g["g1_S_edge_weights"])
+    ids, counts, nv, w, _, _ = co.walk_sample(cg, [0, 1, 2, 3, 4], 4, 3, 20, philox=(99, 0))
+    assert np.array_equal(b.ids.cpu().numpy(), ids) and np.array_equal(b.counts.cpu().numpy(), counts)
+    assert np.array_equal(b.nvalid.cpu().numpy(), nv)
+
+
+@pytest.mark.parametrize("weights", ["half", "float", None])
+def test_csr_cdf_bit_exact_vs_oracle(weights):
+    from oracle import c_oracle as co
+    from pinsage_hip.graph import DeviceGraph
+    rs = np.random.RandomState(5)
+    ei, ew = bipartite_graph(300, 200, 20000, 11, weights)
+    # a hub row longer than numpy's 8192-element summation buffer
+    hub_u = np.arange(9000) % 200 + 300
+    extra = np.stack([np.concatenate([hub_u, np.zeros(9000, dtype=np.int64)]),
+                      np.concatenate([np.zeros(9000, dtype=np.int64), hub_u])])
+    ei = np.concatenate([ei, extra], axis=1)
+    if ew is not None:
+        xw = (rs.random_sample(9000) * 4.9 + 0.1).astype(np.float32) if weights == "float" else \
+            rs.randint(1, 11, size=9000).astype(np.float32) * 0.5
+        ew = np.concatenate([ew, xw, xw])
+    g = DeviceGraph(torch.from_numpy(ei), None if ew is None else torch.from_numpy(ew))
+    cg = co.Graph(ei, ew, threads=4)
+    assert np.array_equal(g.rowptr.cpu().numpy(), cg.rowptr)
+    assert np.array_equal(g.col.cpu().numpy(), cg.col)
+    assert np.array_equal(g.cdf.cpu().numpy(), cg.cdf)          # fp64 bit-exact incl. the hub row
+    assert not g.has_reachable_sink and g.max_degree == int(np.diff(cg.rowptr).max())
+
+
+@pytest.mark.parametrize("W,L,T", [(100, 2, 10), (100, 2, 50), (64, 1, 5), (33, 5, 7), (200, 3, 20), (1, 1, 1)])
+def test_sampler_vs_c_oracle_seeded(W, L, T):
+    from oracle import c_oracle as co
+    from utils.random_walk import RandomWalkSampler
+    ei, ew = bipartite_graph(2000, 1500, 120000, 3, "half")
+    cg = co.Graph(ei, ew, threads=4)
+    nodes = np.arange(2000)
+    uoff, n = cg.uniform_offsets(nodes, W, L)
+    rs = np.random.RandomState(42)
+    u = rs.random_sample(n)
+    ids, counts, nv, w, _, _ = co.walk_sample(cg, nodes, T, L, W, uniforms=u, uoff=uoff, threads=8)
+    s = RandomWalkSampler(torch.from_numpy(ei), torch.from_numpy(ew), walk_length=L, num_walks=W)
+    np.random.seed(42)
+    b = s.sample_batch(nodes, T)
+    assert np.array_equal(b.ids.cpu().numpy(), ids)
+    assert np.array_equal(b.counts.cpu().numpy(), counts)
+    assert np.array_equal(b.nvalid.cpu().numpy(), nv)
+    assert np.array_equal(b.host()[3], w)
+    assert np.random.random_sample() == rs.random_sample()
+    # philox mode, same graph
+    s2 = RandomWalkSampler(torch.from_numpy(ei), torch.from_numpy(ew), walk_length=L, num_walks=W, rng="philox", seed=7)
+    s2.sample_batch(nodes[:3], T)                                  # call 0
+    b2 = s2.sample_batch(nodes, T)                                 # call 1
+    ids2, counts2, nv2, _, _, _ = co.walk_sample(cg, nodes, T, L, W, philox=(7, 1), threads=8)
+    assert np.array_equal(b2.ids.cpu().numpy(), ids2) and np.array_equal(b2.counts.cpu().numpy(), counts2)
+
+
+def test_sampler_determinism_and_errors():
+    from utils.random_walk import RandomWalkSampler
+    ei, ew = bipartite_graph(500, 300, 20000, 9, "half")
+    s = RandomWalkSampler(torch.from_numpy(ei), torch.from_numpy(ew), rng="philox", seed=1)
+    a = s.sample_batch(np.arange(500), 10)
+    s._calls = 0
+    b = s.sample_batch(np.arange(500), 10)
+    assert torch.equal(a.ids, b.ids) and torch.equal(a.counts, b.counts)
+    with pytest.raises(IndexError):
+        s.batch_sample_neighbors([0, 800], 10)                     # reference: adj_list[800] IndexError
+    nb, wt = s.batch_sample_neighbors([], 10)
+    assert len(nb) == 0 and list(nb) == []
+
+
+def test_importance_pool_golden_and_oracle(golden):
+    from oracle import c_oracle as co
+    from pinsage_hip import sampling
+    from test_oracle_golden import _counts_from_weights
+    g = golden
+    counts = _counts_from_weights(g["g2_weights"], g["g2_nvalid"])
+    dev = torch.device("cuda")
+    ids = torch.from_numpy(g["g2_ids"].astype(np.int32)).to(dev)
+    cn = torch.from_numpy(counts).to(dev)
+    nvl = torch.from_numpy(g["g2_nvalid"]).to(dev)
+    for tag in ("items", "all"):
+        x = torch.from_numpy(g[f"g2_h_{tag}"]).to(dev)
+        out = sampling.importance_pool(x, ids=ids, counts=cn, nvalid=nvl)
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"g2_out_{tag}"], rtol=1e-5, atol=1e-6)
+    # larger seeded case vs the C oracle, H = 256 (one 1 KiB row per wave instruction) and odd H
+    rs = np.random.RandomState(0)
+    for H in (256, 100, 7):
+        N, B, T = 5000, 3000, 50
+        x = rs.standard_normal((N, H)).astype(np.float32)
+        idn = rs.randint(0, 2 * N, size=(B, T)).astype(np.int64)   # ~half out of range (user ids dropped)
+        cnt = rs.randint(1, 20, size=(B, T)).astype(np.int32)
+        nvv = rs.randint(0, T + 1, size=B).astype(np.int32)
+        ref = co.importance_pool(x, idn, cnt, nvv, threads=8)
+        out = sampling.importance_pool(torch.from_numpy(x).to(dev), ids=torch.from_numpy(idn.astype(np.int32)).to(dev),
+                                       counts=torch.from_numpy(cnt).to(dev), nvalid=torch.from_numpy(nvv).to(dev))
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
