@@ -1,0 +1,284 @@
+// dense_mfma.hip -- fp32 MFMA GEMM for gfx950 with fused epilogues.
+//
+//   ps_linear     : y = epi( x W^T (+ x2 W2^T) + b ), epi = bias / ReLU / row L2-normalise.
+//                   Replaces the nn.Linear + F.relu + torch.cat + F.normalize chain of
+//                   PinSage.forward (reference model/pinsage.py:202, 235-240, 248-249).
+//   ps_lsh_encode : codes = bitpack( x A^T >= 0 ), the random-hyperplane projection of
+//                   faiss.IndexLSH (reference utils/nearest_neighbors.py:26,43,66) with a wavefront
+//                   ballot bit-pack epilogue (LSB-first bytes, faiss fvec2bitvec).
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32, i.e. an exact fp32 fma chain with k ascending and one
+// accumulator per output (no split-K) -- bit-identical to `acc = fmaf(x[k], w[k], acc)`, which is
+// what the CPU oracle evaluates, so LSH sign decisions are bit-exact.
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN = (WM*TM*32) x (WN*TN*32), K step 32.
+// LDS image per operand row: [4 groups of 8 k][lane-half h][4] so that the lane (row i, half h)
+// fetches its four k values of one group (k = 8g + 2t + h, t = 0..3) with a single ds_read_b128;
+// row stride 36 floats (144 B) keeps the b128 reads bank-conflict free.  The k-permutation is done
+// in registers while staging (two float4 global loads per row-group), global loads for the next
+// K step are in flight while the current one is multiplied.
+#include "ps_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDS_STRIDE = 36;
+
+struct GemmArgs {
+    const float *x;  int64_t M; int K;  const float *W;  int ldw;
+    const float *x2; int K2;            const float *W2; int ldw2;
+    const float *bias; int N; int flags;
+    float *y;            // EPI 0
+    uint8_t *codes; int cs;  // EPI 1
+};
+
+// 8 consecutive k of one row (zero-filled outside [0,K) / invalid row)
+__device__ __forceinline__ void load8(const float *base, bool row_ok, int k, int K, bool vec_ok, float (&v)[8]) {
+    if (row_ok && vec_ok && k + 8 <= K) {
+        const float4 a = *reinterpret_cast<const float4 *>(base + k);
+        const float4 b = *reinterpret_cast<const float4 *>(base + k + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (row_ok && k + j < K) ? base[k + j] : 0.f;
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_ITEMS = BM * 4 / 256, B_ITEMS = BN * 4 / 256;   // (row, group) items per thread
+    static_assert(BM * 4 % 256 == 0 && BN * 4 % 256 == 0, "tile/thread mismatch");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_STRIDE + BM * WN];
+    float *sA = smem, *sB = smem + BM * LDS_STRIDE, *sRed = smem + (BM + BN) * LDS_STRIDE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int phase = 0; phase < 2; ++phase) {
+        const float *X = phase == 0 ? g.x : g.x2;
+        const float *Wp = phase == 0 ? g.W : g.W2;
+        const int K = phase == 0 ? g.K : g.K2;
+        const int ldw = phase == 0 ? g.ldw : g.ldw2;
+        if (X == nullptr || K <= 0) continue;
+        const bool vecA = (K % 4 == 0) && (reinterpret_cast<size_t>(X) % 16 == 0);
+        const bool vecB = (ldw % 4 == 0) && (reinterpret_cast<size_t>(Wp) % 16 == 0);
+
+        float ra[A_ITEMS][8], rb[B_ITEMS][8];
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int q = 0; q < A_ITEMS; ++q) {
+                const int it = tid + 256 * q, row = it >> 2, grp = it & 3;
+                const int64_t m = m0 + row;
+                load8(X + m * K, m < g.M, k0 + grp * 8, K, vecA, ra[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < B_ITEMS; ++q) {
+                const int it = tid + 256 * q, row = it >> 2, grp = it & 3;
+                const int n = n0 + row;
+                load8(Wp + (int64_t)n * ldw, n < g.N, k0 + grp * 8, K, vecB, rb[q]);
+            }
+        };
+        auto stash = [&]() {
+#pragma unroll
+            for (int q = 0; q < A_ITEMS; ++q) {
+                const int it = tid + 256 * q, row = it >> 2, grp = it & 3;
+                float *d = sA + row * LDS_STRIDE + grp * 8;
+                *reinterpret_cast<float4 *>(d) = make_float4(ra[q][0], ra[q][2], ra[q][4], ra[q][6]);
+                *reinterpret_cast<float4 *>(d + 4) = make_float4(ra[q][1], ra[q][3], ra[q][5], ra[q][7]);
+            }
+#pragma unroll
+            for (int q = 0; q < B_ITEMS; ++q) {
+                const int it = tid + 256 * q, row = it >> 2, grp = it & 3;
+                float *d = sB + row * LDS_STRIDE + grp * 8;
+                *reinterpret_cast<float4 *>(d) = make_float4(rb[q][0], rb[q][2], rb[q][4], rb[q][6]);
+                *reinterpret_cast<float4 *>(d + 4) = make_float4(rb[q][1], rb[q][3], rb[q][5], rb[q][7]);
+            }
+        };
+
+        fetch(0);
+        for (int k0 = 0; k0 < K; k0 += BK) {
+            __syncthreads();           // previous step's fragment reads are done
+            stash();
+            __syncthreads();
+            if (k0 + BK < K) fetch(k0 + BK);
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                float4 fa[TM], fb[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+                    fa[a] = *reinterpret_cast<const float4 *>(sA + ((wm * TM + a) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    fb[b] = *reinterpret_cast<const float4 *>(sB + ((wn * TN + b) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const float av = t == 0 ? fa[a].x : t == 1 ? fa[a].y : t == 2 ? fa[a].z : fa[a].w;
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            const float bv = t == 0 ? fb[b].x : t == 1 ? fb[b].y : t == 2 ? fb[b].z : fb[b].w;
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ------------------------------ epilogue -------------------------------------------------
+    // C layout (32x32 tile): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (EPI == 1) {
+        uint32_t *codes32 = reinterpret_cast<uint32_t *>(g.codes);
+        const int words = g.cs >> 2;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int colbase = n0 + (wn * TN + b) * 32;
+                const bool col_ok = colbase + li < g.N;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t mask = __ballot(col_ok && acc[a][b][r] >= 0.f);   // bit = (xt >= 0)
+                    const int64_t row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (li == 0 && row < g.M && colbase < g.N)
+                        codes32[row * words + (colbase >> 5)] = lh ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+                }
+            }
+        return;
+    }
+
+    const bool relu = g.flags & PS_RELU, l2 = g.flags & PS_L2NORM;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + (wn * TN + b) * 32 + li;
+        const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[a][b][r] + bv;
+                if (relu) v = v > 0.f ? v : 0.f;
+                if (col >= g.N) v = 0.f;
+                acc[a][b][r] = v;
+            }
+    }
+    if (l2) {   // F.normalize(p=2, dim=1, eps=1e-12): x / max(||x||, eps); the block holds whole rows
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float ss = 0.f;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) ss = fmaf(acc[a][b][r], acc[a][b][r], ss);
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);   // over the 32 columns of the half
+                const int rowl = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (li == 0) sRed[rowl * WN + wn] = ss;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowl = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float ss = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) ss += sRed[rowl * WN + w];
+                float nrm = sqrtf(ss);
+                nrm = nrm > 1e-12f ? nrm : 1e-12f;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b][r] = acc[a][b][r] / nrm;
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row >= g.M) continue;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = n0 + (wn * TN + b) * 32 + li;
+                if (col < g.N) g.y[row * g.N + col] = acc[a][b][r];
+            }
+        }
+}
+
+__global__ void l2norm_rows_kernel(float *y, int64_t M, int N) {   // N > 256 only
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t m = wave; m < M; m += nw) {
+        float ss = 0.f;
+        for (int n = lane; n < N; n += 64) ss = fmaf(y[m * N + n], y[m * N + n], ss);
+        ss = ps_wave_sum_f32(ss);
+        float nrm = sqrtf(ss);
+        nrm = nrm > 1e-12f ? nrm : 1e-12f;
+        for (int n = lane; n < N; n += 64) y[m * N + n] = y[m * N + n] / nrm;
+    }
+}
+
+template <int EPI>
+int launch_gemm(const GemmArgs &g, hipStream_t st) {
+    if (g.N <= 64) {
+        dim3 grid((unsigned)ps_cdiv(g.M, 64), 1);
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 1, EPI>), grid, dim3(256), 0, st, g);
+    } else if (g.N <= 128) {
+        dim3 grid((unsigned)ps_cdiv(g.M, 64), 1);
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, EPI>), grid, dim3(256), 0, st, g);
+    } else {
+        dim3 grid((unsigned)ps_cdiv(g.M, 64), (unsigned)ps_cdiv(g.N, 256));
+        hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 2, 2, EPI>), grid, dim3(256), 0, st, g);
+    }
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+}  // namespace
+
+extern "C" int ps_linear(const float *x, int64_t M, int K, const float *W, int ldw, const float *b, int N,
+                         const float *x2, int K2, const float *W2, int ldw2, int flags, float *y, ps_stream_t stream) {
+    if (M < 0 || K <= 0 || N <= 0 || ldw < K) return PS_EINVAL;
+    if (M == 0) return PS_OK;
+    if (!x || !W || !y) return PS_EINVAL;
+    if (x2 && (!W2 || K2 <= 0 || ldw2 < K2)) return PS_EINVAL;
+    if (M > (int64_t)0x7fffffff * 64) return PS_EINVAL;
+    hipStream_t st = ps_stream(stream);
+    GemmArgs g{x, M, K, W, ldw, x2, x2 ? K2 : 0, W2, ldw2, b, N, flags, y, nullptr, 0};
+    const bool fused_norm = N <= 256;
+    if (!fused_norm) g.flags &= ~PS_L2NORM;
+    int rc = launch_gemm<0>(g, st);
+    if (rc != PS_OK) return rc;
+    if ((flags & PS_L2NORM) && !fused_norm) {
+        int64_t grid = ps_cdiv(M, 4);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)grid), dim3(256), 0, st, y, M, N);
+        PS_CHECK_LAUNCH();
+    }
+    return PS_OK;
+}
+
+extern "C" int ps_lsh_encode(const float *x, int64_t N, int D, const float *A, int nbits, uint8_t *codes,
+                             ps_stream_t stream) {
+    if (N < 0 || D <= 0 || nbits <= 0) return PS_EINVAL;
+    if (nbits % 32 != 0) return PS_EUNSUPPORTED;      // codes are written as whole 32-bit ballot words
+    if (N == 0) return PS_OK;
+    if (!x || !A || !codes || reinterpret_cast<size_t>(codes) % 4 != 0) return PS_EINVAL;
+    GemmArgs g{x, N, D, A, D, nullptr, 0, nullptr, 0, nullptr, nbits, 0, nullptr, codes, nbits / 8};
+    return launch_gemm<1>(g, ps_stream(stream));
+}

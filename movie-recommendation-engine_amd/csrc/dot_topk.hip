@@ -1,0 +1,119 @@
+// dot_topk.hip -- exact (brute-force) cosine/dot top-k on gfx950.
+//
+// Replaces the exact search of the reference: `sim = E[q] @ E.T; sim[q] = -inf; torch.topk(sim, k)`
+// (inference.py:112-118, utils/evaluation.py:106-132, main.py:226-230, demo.py:150-163).
+// Queries are processed in chunks: gather the query rows, one fp32-MFMA GEMM (ps_linear's kernel,
+// k-ordered fma chain) into a [chunk, N] similarity slab in the workspace, then one wave per query
+// row selects the k best: every lane keeps a sorted k-list of its strided elements in an LDS
+// column, and the 64 columns are merged by k wave-wide min-reductions.
+// Order: similarity descending, ties by ascending id (torch.topk leaves tie order unspecified).
+#include "ps_common.h"
+
+namespace {
+
+constexpr uint64_t EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+
+__global__ void gather_rows_kernel(const float *__restrict__ E, int D, const int64_t *__restrict__ qidx, int64_t nq,
+                                   float *__restrict__ Q) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq * D; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D;
+        Q[i] = E[qidx[r] * D + (i - r * D)];
+    }
+}
+
+__device__ __forceinline__ uint32_t desc_key(float v) {      // smaller key = larger value
+    const uint32_t b = __float_as_uint(v);
+    const uint32_t u = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // monotone increasing in v
+    return ~u;
+}
+__device__ __forceinline__ float key_value(uint32_t kk) {
+    const uint32_t u = ~kk;
+    const uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(b);
+}
+
+__global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__ sims, int64_t N, int64_t rows,
+                                                       const int64_t *__restrict__ qidx, int exclude_self, int k,
+                                                       float *__restrict__ vals, int64_t *__restrict__ ids) {
+    extern __shared__ uint64_t skeys[];   // [4 waves][k][64]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint64_t *col = skeys + (size_t)wv * k * 64 + lane;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    if (row >= rows) return;
+    const float *s = sims + row * N;
+    const int64_t self = exclude_self ? qidx[row] : -1;
+    for (int p = 0; p < k; ++p) col[p * 64] = EMPTY_KEY;
+    uint64_t worst = EMPTY_KEY;
+    int filled = 0;
+    for (int64_t j = lane; j < N; j += 64) {
+        float v = s[j];
+        if (j == self) v = -INFINITY;
+        const uint64_t key = ((uint64_t)desc_key(v) << 32) | (uint32_t)j;
+        if (key < worst) {
+            int p = filled < k ? filled : k - 1;
+            while (p > 0 && col[(p - 1) * 64] > key) { col[p * 64] = col[(p - 1) * 64]; --p; }
+            col[p * 64] = key;
+            if (filled < k) ++filled;
+            if (filled == k) worst = col[(k - 1) * 64];
+        }
+    }
+    int head = 0;
+    for (int r = 0; r < k; ++r) {
+        uint64_t mine = head < filled ? col[head * 64] : EMPTY_KEY;
+        uint64_t best = mine;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)best, o, 64);
+            const uint32_t hi = __shfl_xor((uint32_t)(best >> 32), o, 64);
+            const uint64_t other = ((uint64_t)hi << 32) | lo;
+            best = other < best ? other : best;
+        }
+        if (mine == best && best != EMPTY_KEY) ++head;      // keys are unique (id in the low word)
+        if (lane == 0) {
+            vals[row * k + r] = best != EMPTY_KEY ? key_value((uint32_t)(best >> 32)) : -INFINITY;
+            ids[row * k + r] = best != EMPTY_KEY ? (int64_t)(uint32_t)best : -1;
+        }
+    }
+}
+
+int64_t chunk_rows(int64_t nq, int64_t N) {
+    int64_t c = ((int64_t)1 << 28) / (N > 0 ? N : 1);
+    if (c < 64) c = 64;
+    return c < nq ? c : nq;
+}
+
+}  // namespace
+
+extern "C" size_t ps_dot_topk_workspace_bytes(int64_t nq, int64_t N, int D, int k) {
+    if (nq <= 0 || N <= 0) return 256;
+    const int64_t c = chunk_rows(nq, N);
+    return (size_t)c * N * sizeof(float) + (size_t)c * D * sizeof(float) + 1024;
+}
+
+extern "C" int ps_dot_topk(const float *E, int64_t N, int D, const int64_t *qidx, int64_t nq, int k, int exclude_self,
+                           float *vals, int64_t *ids, void *workspace, size_t workspace_bytes, ps_stream_t stream) {
+    if (N < 0 || D <= 0 || nq < 0 || k <= 0) return PS_EINVAL;
+    if (k > 160 || N >= ((int64_t)1 << 32)) return PS_EUNSUPPORTED;
+    if (nq == 0) return PS_OK;
+    if (!E || !qidx || !vals || !ids || !workspace) return PS_EINVAL;
+    if (workspace_bytes < ps_dot_topk_workspace_bytes(nq, N, D, k)) return PS_EWORKSPACE;
+    hipStream_t st = ps_stream(stream);
+    const int64_t c = chunk_rows(nq, N);
+    char *base = reinterpret_cast<char *>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
+    float *sims = reinterpret_cast<float *>(base);
+    float *Q = reinterpret_cast<float *>(base + ((size_t)c * N * sizeof(float) + 255) / 256 * 256);
+    const size_t lds = (size_t)4 * k * 64 * sizeof(uint64_t);
+    for (int64_t q0 = 0; q0 < nq; q0 += c) {
+        const int64_t rows = (nq - q0) < c ? (nq - q0) : c;
+        int64_t g = ps_cdiv(rows * D, 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, E, D, qidx + q0, rows, Q);
+        PS_CHECK_LAUNCH();
+        const int rc = ps_linear(Q, rows, D, E, D, nullptr, (int)N, nullptr, 0, nullptr, 0, 0, sims, stream);
+        if (rc != PS_OK) return rc;
+        hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), lds, st, sims, N, rows,
+                           qidx + q0, exclude_self, k, vals + q0 * k, ids + q0 * k);
+        PS_CHECK_LAUNCH();
+    }
+    return PS_OK;
+}

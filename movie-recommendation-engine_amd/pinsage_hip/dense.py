@@ -1,0 +1,142 @@
+"""Dense / retrieval ops over libpinsage_hip.so: fp32-MFMA linear layers with fused epilogues,
+LSH encode (projection + ballot bit-pack), Hamming top-k, exact dot top-k."""
+from __future__ import annotations
+
+import torch
+
+from . import native as nv
+
+
+def _rowmajor(w):
+    """(tensor to keep alive, leading dimension) for a 2-D fp32 matrix whose rows are contiguous
+    (column slices of a row-major weight are fine: no copy, ld = stride(0))."""
+    if w.dtype != torch.float32:
+        raise TypeError("fp32 expected")
+    if w.dim() != 2:
+        raise ValueError("2-D matrix expected")
+    if w.stride(1) != 1 or w.stride(0) < w.size(1):
+        w = w.contiguous()
+    return w, int(w.stride(0)) if w.size(0) > 1 else max(int(w.stride(0)), int(w.size(1)))
+
+
+def _ptr_view(t):
+    if t is None:
+        return nv.C.c_void_p(0)
+    if not t.is_cuda:
+        raise nv.NativeError("device tensor expected")
+    return nv.C.c_void_p(t.data_ptr())
+
+
+def linear(x, W, b=None, x2=None, W2=None, relu=False, l2norm=False):
+    """y = epi(x @ W.T (+ x2 @ W2.T) + b): nn.Linear / F.relu / torch.cat / F.normalize of
+    PinSage.forward (reference model/pinsage.py:202,235-240,248-249) in one kernel."""
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        raise TypeError("fp32 expected")
+    M, K = int(x.size(0)), int(x.size(1))
+    Wk, ldw = _rowmajor(W)
+    N = int(Wk.size(0))
+    if int(Wk.size(1)) != K:
+        raise ValueError(f"shape mismatch: x [{M},{K}] vs W {tuple(Wk.shape)}")
+    K2, ldw2, W2k = 0, 0, None
+    if x2 is not None:
+        x2 = x2.contiguous()
+        W2k, ldw2 = _rowmajor(W2)
+        K2 = int(x2.size(1))
+        if int(W2k.size(1)) != K2 or int(W2k.size(0)) != N or int(x2.size(0)) != M:
+            raise ValueError("shape mismatch in the second operand pair")
+    if b is not None:
+        b = b.contiguous()
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    flags = (nv.PS_RELU if relu else 0) | (nv.PS_L2NORM if l2norm else 0)
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib().ps_linear(nv.ptr(x), nv.i64(M), nv.i32(K), _ptr_view(Wk), nv.i32(ldw), nv.ptr(b), nv.i32(N),
+                                    nv.ptr(x2), nv.i32(K2), _ptr_view(W2k), nv.i32(ldw2), nv.i32(flags), nv.ptr(y),
+                                    nv.stream()), "ps_linear")
+    return y
+
+
+def lsh_encode(x, A):
+    """codes uint8[n, nbits/8]: bit j = (x . A[j] >= 0), LSB first (faiss IndexLSH.sa_encode)."""
+    x = x.contiguous()
+    A = A.contiguous()
+    n, d = int(x.size(0)), int(x.size(1))
+    nbits = int(A.size(0))
+    if int(A.size(1)) != d:
+        raise ValueError("projection matrix must be [nbits, dim]")
+    codes = torch.empty((n, nbits // 8), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib().ps_lsh_encode(nv.ptr(x), nv.i64(n), nv.i32(d), nv.ptr(A), nv.i32(nbits), nv.ptr(codes),
+                                        nv.stream()), "ps_lsh_encode")
+    return codes
+
+
+def hamming_topk(qcodes, codes, k, id_offset=0):
+    """-> (dist int32[nq,k], ids int64[nq,k]): k smallest by (distance, id), ascending."""
+    qcodes = qcodes.contiguous()
+    codes = codes.contiguous()
+    nq, cs = int(qcodes.size(0)), int(qcodes.size(1))
+    N = int(codes.size(0))
+    dist = torch.empty((nq, k), dtype=torch.int32, device=qcodes.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=qcodes.device)
+    L = nv.lib()
+    wsb = int(L.ps_hamming_topk_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(cs), nv.i32(k)))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=qcodes.device)
+    with torch.cuda.device(qcodes.device):
+        nv.check(L.ps_hamming_topk(nv.ptr(qcodes), nv.i64(nq), nv.ptr(codes) if N else nv.C.c_void_p(0), nv.i64(N),
+                                   nv.i32(cs), nv.i32(k), nv.i64(id_offset), nv.ptr(dist), nv.ptr(ids), nv.ptr(ws),
+                                   nv.C.c_size_t(wsb), nv.stream()), "ps_hamming_topk")
+    return dist, ids
+
+
+def topk_merge(dist_in, ids_in):
+    """[P, nq, k] candidate lists -> global [nq, k] by (distance, id)."""
+    dist_in = dist_in.contiguous()
+    ids_in = ids_in.contiguous()
+    P, nq, k = [int(v) for v in dist_in.shape]
+    dist = torch.empty((nq, k), dtype=torch.int32, device=dist_in.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=dist_in.device)
+    with torch.cuda.device(dist_in.device):
+        nv.check(nv.lib().ps_topk_merge(nv.ptr(dist_in), nv.ptr(ids_in), nv.i32(P), nv.i64(nq), nv.i32(k), nv.ptr(dist),
+                                        nv.ptr(ids), nv.stream()), "ps_topk_merge")
+    return dist, ids
+
+
+def dot_topk(E, qidx, k, exclude_self=True):
+    """Exact search: top-k of E[q] @ E.T per query row index (reference inference.py:112-118)."""
+    E = E.contiguous()
+    qidx = qidx.to(device=E.device, dtype=torch.int64).contiguous()
+    N, D = int(E.size(0)), int(E.size(1))
+    nq = int(qidx.numel())
+    vals = torch.empty((nq, k), dtype=torch.float32, device=E.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=E.device)
+    L = nv.lib()
+    wsb = int(L.ps_dot_topk_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(D), nv.i32(k)))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=E.device)
+    with torch.cuda.device(E.device):
+        nv.check(L.ps_dot_topk(nv.ptr(E), nv.i64(N), nv.i32(D), nv.ptr(qidx), nv.i64(nq), nv.i32(k),
+                               nv.i32(int(exclude_self)), nv.ptr(vals), nv.ptr(ids), nv.ptr(ws), nv.C.c_size_t(wsb),
+                               nv.stream()), "ps_dot_topk")
+    return vals, ids
+
+
+def mt19937_random_sample(n, device):
+    """n doubles of the process-global numpy legacy stream generated ON THE DEVICE; the global
+    np.random state is advanced exactly as `np.random.random_sample(n)` would (reference
+    utils/random_walk.py:79 draws these one at a time)."""
+    import numpy as np
+    name, key, pos, has_gauss, cached = np.random.get_state()
+    if name != "MT19937":
+        raise RuntimeError("numpy global RNG is not MT19937")
+    dev = torch.device(device)
+    st_in = torch.from_numpy(key.astype(np.uint32).view(np.int32)).to(dev)
+    st_out = torch.empty(624, dtype=torch.int32, device=dev)
+    pos_out = torch.empty(1, dtype=torch.int32, device=dev)
+    out = torch.empty(int(n), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        nv.check(nv.lib().ps_mt19937_random_sample(nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(n)), nv.ptr(out),
+                                                   nv.ptr(st_out), nv.ptr(pos_out), nv.stream()),
+                 "ps_mt19937_random_sample")
+    new_key = st_out.cpu().numpy().view(np.uint32)
+    np.random.set_state((name, new_key, int(pos_out.item()), has_gauss, cached))
+    return out

@@ -1,0 +1,232 @@
+"""GPU parity of the pooled forward, dense layers, aggregators, LSH and exact search: HIP kernels
+through the reference-shaped classes vs the reference's golden outputs and the CPU oracle.
+Tolerances: fp32 embeddings rtol 1e-5 / atol 2e-6 (north_star: 1e-5 rel); codes / ids bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bipartite_graph
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-5, 2e-6
+
+
+def _model_from_golden(g):
+    from model.pinsage import PinSage
+    m = PinSage(16, 32, 8, num_layers=2)
+    sd = {k[len("g3_param_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("g3_param_")}
+    assert set(sd) == set(m.state_dict())                      # same parameter names as the reference
+    m.load_state_dict(sd)
+    return m.eval()
+
+
+def _lists(g, li):
+    ids, w, nv = g[f"g3_l{li}_ids"], g[f"g3_l{li}_weights"], g[f"g3_l{li}_nvalid"]
+    nb = [[np.int64(v) for v in ids[i, :nv[i]]] for i in range(ids.shape[0])]
+    wt = [w[i, :nv[i]].tolist() for i in range(ids.shape[0])]
+    return nb, wt
+
+
+def test_forward_golden_all_branches(golden):
+    g = golden
+    m = _model_from_golden(g)
+    x = torch.from_numpy(g["g3_x"])
+    l0, l1 = _lists(g, 0), _lists(g, 1)
+    for dev in ("cpu", "cuda"):                                 # CPU tensors are staged through the GPU
+        mm, xx = m.to(dev), x.to(dev)
+        with torch.no_grad():
+            e = mm(xx, edge_index=None, sampled_neighbors=[l0[0], l1[0]], importance_weights=[l0[1], l1[1]])
+            np.testing.assert_allclose(e.cpu().numpy(), g["g3_e_pool"], rtol=RTOL, atol=ATOL)
+            e = mm(xx, edge_index=None, sampled_neighbors=tuple(l0[0]), importance_weights=tuple(l0[1]))
+            np.testing.assert_allclose(e.cpu().numpy(), g["g3_e_shared"], rtol=RTOL, atol=ATOL)
+            e = mm(xx)
+            np.testing.assert_allclose(e.cpu().numpy(), g["g3_e_mlp"], rtol=RTOL, atol=ATOL)
+            with pytest.warns(UserWarning) if dev == "cpu" else _nullcontext():
+                e = mm(xx, [l0[0], l1[0]], [l0[1], l1[1]])      # the drivers' positional call form
+            np.testing.assert_allclose(e.cpu().numpy(), g["g3_e_pool"], rtol=RTOL, atol=ATOL)
+        # autograd-enabled pooled branch (pool kernel forward + torch dense layers)
+        e = mm(xx, edge_index=None, sampled_neighbors=[l0[0], l1[0]], importance_weights=[l0[1], l1[1]])
+        np.testing.assert_allclose(e.detach().cpu().numpy(), g["g3_e_pool"], rtol=RTOL, atol=ATOL)
+        e.sum().backward()
+        assert mm.convs[0].lin_update.weight.grad is not None and mm.input_proj.weight.grad.abs().sum() > 0
+        mm.zero_grad()
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def test_get_embeddings_golden(golden):
+    from utils.random_walk import RandomWalkSampler
+    g = golden
+    m = _model_from_golden(g).cuda()
+    s = RandomWalkSampler(torch.from_numpy(g["g3_edge_index"]), torch.from_numpy(g["g3_edge_weights"]),
+                          walk_length=2, num_walks=100)
+    np.random.seed(5)
+    with torch.no_grad():
+        e = m.get_embeddings(torch.from_numpy(g["g3_x"]).cuda(), s, num_neighbors=10)
+    np.testing.assert_allclose(e.cpu().numpy(), g["g3_e_get"], rtol=RTOL, atol=ATOL)
+
+
+def test_importance_pooling_list_api_golden(golden):
+    from model.pinsage import ImportancePooling
+    g = golden
+    pool = ImportancePooling()
+    h = torch.from_numpy(g["g2_h_items"]).cuda()
+    odd_n = [3, [1, 2, 40], [], [5, 6, 7]]
+    odd_w = [0.3, [0.5, 0.25, 0.25], [], [0.7]]
+    np.testing.assert_allclose(pool(h, odd_n, odd_w).cpu().numpy(), g["g2_odd_out"], rtol=RTOL, atol=ATOL)
+    ids, w, nv = g["g2_ids"], g["g2_weights"], g["g2_nvalid"]
+    nb = [[np.int64(v) for v in ids[i, :nv[i]]] for i in range(30)]
+    wt = [w[i, :nv[i]].tolist() for i in range(30)]
+    for tag in ("items", "all"):
+        out = pool(torch.from_numpy(g[f"g2_h_{tag}"]).cuda(), nb, wt)
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"g2_out_{tag}"], rtol=RTOL, atol=ATOL)
+
+
+def test_pool_backward_matches_torch():
+    from model.pinsage import ImportancePooling
+    torch.manual_seed(0)
+    x = torch.randn(40, 24, device="cuda", requires_grad=True)
+    nb = [[int(v) for v in np.random.RandomState(i).randint(0, 60, size=i % 7)] for i in range(40)]
+    wt = [[float(v) for v in np.random.RandomState(100 + i).random_sample(i % 7) + 0.1] for i in range(40)]
+    out = ImportancePooling()(x, nb, wt)
+    out.pow(2).sum().backward()
+    gx = x.grad.clone()
+    x2 = x.detach().clone().requires_grad_(True)
+    rows = []
+    for a, b in zip(nb, wt):
+        v = [(i, w) for i, w in zip(a, b) if i <= 39]
+        if not v:
+            rows.append(torch.zeros(24, device="cuda"))
+            continue
+        wv = torch.tensor([w for _, w in v], device="cuda")
+        wv = wv / wv.sum()
+        rows.append((x2[[i for i, _ in v]] * wv[:, None]).sum(0))
+    torch.stack(rows).pow(2).sum().backward()
+    np.testing.assert_allclose(gx.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,K,N,K2", [(1000, 128, 256, 0), (777, 256, 256, 256), (513, 256, 128, 0), (300, 256, 64, 0),
+                                        (65, 20, 6, 0), (129, 33, 300, 7), (5000, 16, 32, 32)])
+def test_linear_vs_oracle(M, K, N, K2):
+    from oracle import c_oracle as co
+    from pinsage_hip import dense
+    rs = np.random.RandomState(M + N)
+    x = rs.standard_normal((M, K)).astype(np.float32)
+    Wfull = (rs.standard_normal((N, K + K2)) / np.sqrt(K + K2)).astype(np.float32)
+    b = rs.standard_normal(N).astype(np.float32)
+    x2 = rs.standard_normal((M, K2)).astype(np.float32) if K2 else None
+    Wd = torch.from_numpy(Wfull).cuda()
+    for relu, l2 in ((False, False), (True, False), (True, True)):
+        ref = co.linear(x, np.ascontiguousarray(Wfull[:, :K]), b, x2=x2,
+                        W2=np.ascontiguousarray(Wfull[:, K:]) if K2 else None, relu=relu, l2norm=l2, threads=8)
+        y = dense.linear(torch.from_numpy(x).cuda(), Wd[:, :K], torch.from_numpy(b).cuda(),
+                         x2=torch.from_numpy(x2).cuda() if K2 else None, W2=Wd[:, K:] if K2 else None,
+                         relu=relu, l2norm=l2)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+        if not l2:
+            # same k-ordered fma chain as the oracle: results are in fact bit-identical before the norm
+            assert np.array_equal(y.cpu().numpy(), ref)
+
+
+def test_aggregators_golden(golden):
+    from model import aggregators as A
+    g = golden
+    f = torch.from_numpy(g["g4_features"]).cuda()
+    nbrs = [[1, 2, 3], [], [0], [4, 5, 6, 7, 8], [9, 10], [11, 0, 1]]
+    wts = [[0.5, 0.25, 0.25], [], [2.0], [1.0, 2.0, 3.0, 4.0, 5.0], [0.0, 0.0], [0.1, 0.7, 0.2]]
+    ia, at, mp = A.ImportanceAggregator(8, 6), A.AttentionAggregator(8), A.MaxPoolingAggregator(8, 6)
+    for nm, m in (("ia", ia), ("at", at), ("mp", mp)):
+        sd = {k[len(f"g4_{nm}_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"g4_{nm}_")}
+        assert set(sd) == set(m.state_dict())
+        m.load_state_dict(sd)
+        m.cuda().eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(A.MeanAggregator()(f, nbrs).cpu().numpy(), g["g4_mean"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(A.WeightedAggregator()(f, nbrs, wts).cpu().numpy(), g["g4_weighted"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(ia(f, nbrs, wts).cpu().numpy(), g["g4_importance"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(at(f, nbrs).cpu().numpy(), g["g4_attention"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(mp(f, nbrs).cpu().numpy(), g["g4_maxpool"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(IndexError):
+        A.MeanAggregator()(f, [[99]])
+
+
+@pytest.mark.parametrize("d,nbits", [(128, 256), (256, 512), (64, 64), (48, 128)])
+def test_lsh_codes_and_search_bit_exact(d, nbits):
+    from oracle import c_oracle as co
+    from utils.nearest_neighbors import LSHIndex, lsh_rotation_matrix
+    rs = np.random.RandomState(d)
+    N = 3000
+    emb = rs.standard_normal((N, d)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    emb[100] = emb[7]; emb[2500] = emb[7]                       # exact duplicates -> distance ties, id order
+    idx = LSHIndex(d, nbits, 16)
+    idx.build(torch.from_numpy(emb))
+    assert idx.index.ntotal == N
+    A = lsh_rotation_matrix(d, nbits)
+    ref_codes = co.lsh_encode(emb, A, threads=8)
+    assert np.array_equal(idx.index.codes.cpu().numpy(), ref_codes)            # bit-exact codes
+    for k in (1, 10, 11, 50):
+        dist, ids = idx.search(emb[:200], k)
+        rd, ri = co.hamming_topk(ref_codes[:200], ref_codes, k, threads=8)
+        assert dist.dtype == np.float32 and ids.dtype == np.int64
+        assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
+    d1, i1 = idx.search(emb[7:8], 4)
+    assert i1[0, :3].tolist() == [7, 100, 2500] and d1[0, 0] == 0
+    # ntotal < k padding like faiss (-1 ids)
+    small = LSHIndex(d, nbits, 16)
+    small.build(emb[:5])
+    d2, i2 = small.search(emb[:3], 8)
+    assert np.all(i2[:, 5:] == -1) and np.all(i2[:, :5] >= 0)
+
+
+def test_topk_merge_equals_single_shard():
+    from pinsage_hip import dense
+    rs = np.random.RandomState(1)
+    codes = torch.from_numpy(rs.randint(0, 256, size=(4000, 32)).astype(np.uint8)).cuda()
+    q = codes[:300]
+    d0, i0 = dense.hamming_topk(q, codes, 11)
+    parts = [dense.hamming_topk(q, codes[s:s + 1000], 11, id_offset=s) for s in range(0, 4000, 1000)]
+    dm, im = dense.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(dm, d0) and torch.equal(im, i0)
+
+
+def test_exact_topk_golden_and_oracle(golden):
+    from oracle import c_oracle as co
+    from utils.nearest_neighbors import generate_recommendations, ExactIndex
+    g = golden
+    emb = torch.from_numpy(g["g5_emb"])
+    for qi, q in enumerate(g["g5_queries"]):
+        assert np.array_equal(generate_recommendations(emb, int(q), k=11), g["g5_top11"][qi])
+        assert np.array_equal(generate_recommendations(emb, int(q), k=5, exclude_query=False), g["g5_top5_incl"][qi])
+    rs = np.random.RandomState(3)
+    E = rs.standard_normal((5000, 64)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    ex = ExactIndex(64)
+    ex.build(E)
+    q = np.arange(0, 5000, 37)
+    vals, ids = ex.search_indices(q, 11)
+    rv, ri = co.dot_topk(E, q, 11, threads=8)
+    assert np.array_equal(ids.cpu().numpy(), ri)
+    np.testing.assert_allclose(vals.cpu().numpy(), rv, rtol=1e-6, atol=1e-7)
+
+
+def test_device_mt19937_matches_numpy():
+    from pinsage_hip import dense
+    for seed, burn, n in ((42, 0, 5000), (0, 3, 1249), (123, 311, 100000), (7, 1, 1)):
+        np.random.seed(seed)
+        np.random.random_sample(burn)
+        if burn % 2:
+            np.random.randint(0, 10)                               # odd word position
+        st = np.random.get_state()
+        ref = np.random.random_sample(n)
+        tail = np.random.random_sample()
+        np.random.set_state(st)
+        out = dense.mt19937_random_sample(n, "cuda").cpu().numpy()
+        assert np.array_equal(out, ref)
+        assert np.random.random_sample() == tail                   # global state advanced identically
