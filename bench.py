@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline benchmark on MI355X.
+
+One "step" = one pass of the PinSage hot path over the whole synthetic ML-25M-shaped catalogue:
+  embed   : per GCN layer, random-walk neighbour sampling (W=100, L=2, top-T) of every item, then the
+            importance-pooled forward (fp32)                          -> [M, d] unit-norm embeddings
+  index   : LSH encode of all M embeddings (nbits = 2d)               -> [M, nbits/8] codes
+  query   : top-K (K=11) Hamming search of `--queries` item embeddings over all M codes
+with the graph (CSR + fp64 CDF), features and weights resident in HBM.  `value` = M items / step time.
+N > 1: the item catalogue is sharded by id range over N ranks (RCCL all-gather of hidden rows per layer
+and of the [nq, K] candidates), total work fixed -> "scaling": "strong".
+
+Launch: python bench.py --gpus 1 --steps K --warmup W
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "movie-recommendation-engine_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK = 8.0e12          # B/s, spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, v_mfma_f32_32x32x2_f32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dim", type=int, default=256, help="embedding dim d (BASELINE metric: d=256)")
+    ap.add_argument("--T", type=int, default=10, help="neighbours kept per node (north_star: T=10)")
+    ap.add_argument("--lsh-bits", type=int, default=0, help="default 2*dim (256-bit @128, 512-bit @256)")
+    ap.add_argument("--queries", type=int, default=10000)
+    ap.add_argument("--k", type=int, default=11, help="num_recommendations + 1 (inference.py:110)")
+    ap.add_argument("--scale", type=float, default=1.0, help="fraction of ML-25M (tests)")
+    ap.add_argument("--rng", default="philox", choices=["philox", "numpy"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8192)
+    return ap.parse_args()
+
+
+def ceil_log2p1(d):
+    return torch.ceil(torch.log2((d + 1).double())).long()
+
+
+def sampler_algorithmic_bytes(graph, sampler, nodes, T, W, L, call, stream_mode):
+    """per taken step from v: 16 B (int64 rowptr pair) + 8 B * ceil(log2(deg v + 1)) (fp64
+    CDF probes of the binary search) + 4 B (col) [+ 8 B uniform in stream mode]; per start node
+    T * 8 B + 4 B of output.  The walks are replayed exactly with ps_walk_paths (same Philox counters)."""
+    from pinsage_hip import sampling
+    deg = graph.rowptr[1:] - graph.rowptr[:-1]
+    B = nodes.numel()
+    per_step_fixed = 16 + 4 + (8 if stream_mode else 0)
+    d0 = deg[nodes]
+    act = d0 > 0
+    steps = int(act.sum().item()) * W
+    nbytes = int(((ceil_log2p1(d0) * 8 + per_step_fixed) * act).sum().item()) * W
+    if L > 1:
+        starts = nodes.repeat_interleave(W)
+        paths = sampling.walk_paths(graph, starts, L, rng="philox", seed=sampler.seed, call=call, walk_mod=W)
+        for st in range(1, L):
+            src = paths[:, st - 1].long()
+            ok = src >= 0
+            d = deg[src.clamp(min=0)] * ok
+            took = d > 0
+            steps += int(took.sum().item())
+            nbytes += int(((ceil_log2p1(d) * 8 + per_step_fixed) * took).sum().item())
+    nbytes += B * (T * 8 + 4)
+    return nbytes, steps
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from pinsage_hip import synth, dense, sampling
+    from pinsage_hip import native as nv
+    from pinsage_hip.graph import DeviceGraph
+    from pinsage_hip.shard import ShardedPinSage
+    from utils.random_walk import RandomWalkSampler
+    from utils.nearest_neighbors import lsh_rotation_matrix
+    from model.pinsage import PinSage
+
+    U, M, R = [max(8, int(v * a.scale)) for v in
+               (synth.ML25M["num_users"], synth.ML25M["num_items"], synth.ML25M["num_ratings"])]
+    F_IN, HID, D, LAYERS, W, L, T = 128, 256, a.dim, 2, 100, 2, a.T
+    nbits = a.lsh_bits or 2 * D
+    t0 = time.time()
+    ei, ew = synth.bipartite_ratings(U, M, R, seed=20240601, device=dev)
+    graph = DeviceGraph(ei, ew, device=dev)
+    del ei, ew
+    torch.cuda.synchronize()
+    t_graph = time.time() - t0
+    sampler = RandomWalkSampler.from_graph(graph, walk_length=L, num_walks=W, rng=a.rng, seed=42)
+    torch.manual_seed(2)
+    model = PinSage(F_IN, HID, D, LAYERS).to(dev).eval()
+    params = {k: v.detach().float().contiguous() for k, v in model.state_dict().items()}
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    x_full = torch.randn(M, F_IN, generator=gen)
+    A = torch.from_numpy(lsh_rotation_matrix(D, nbits)).to(dev)
+    pipe = ShardedPinSage(params, LAYERS, sampler, M)
+    x_loc = x_full[pipe.lo:pipe.hi].to(dev).contiguous()
+    del x_full
+    nq_local = max(1, a.queries // world)
+    nq = nq_local * world
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    phase_ms = {"embed": 0.0, "index": 0.0, "query": 0.0}
+
+    def step(record=None):
+        if a.rng == "numpy":
+            np.random.seed(42)
+        e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+        e0.record()
+        emb = pipe.embed(x_loc, T)
+        e1.record()
+        pipe.build_index(emb, A)
+        e2.record()
+        d, i = pipe.search(emb[:nq_local], a.k)
+        e3.record()
+        if record is not None:
+            record.append((e0, e1, e2, e3))
+        return emb, d, i
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            step()
+        timer = nv.KernelTimer()
+        recs = []
+        sync_all()
+        nv.set_timer(timer)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            emb, d_out, i_out = step(recs)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        nv.set_timer(None)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    for (e0, e1, e2, e3) in recs:
+        phase_ms["embed"] += e0.elapsed_time(e1)
+        phase_ms["index"] += e1.elapsed_time(e2)
+        phase_ms["query"] += e2.elapsed_time(e3)
+    ms_per_step = elapsed / a.steps * 1e3
+    value = M * a.steps / elapsed
+    ksum = timer.summary()
+
+    out = None
+    if rank == 0:
+        # ---------------- roofline of every kernel (rank 0's shard), algorithmic bytes / flops ---------
+        nodes = torch.arange(pipe.lo, pipe.hi, dtype=torch.int64, device=dev)
+        n_loc = nodes.numel()
+        stream_mode = a.rng == "numpy"
+        sb0, steps0 = sampler_algorithmic_bytes(graph, sampler, nodes, T, W, L, 0, stream_mode)
+        sb1, steps1 = sampler_algorithmic_bytes(graph, sampler, nodes, T, W, L, 1, stream_mode)
+        samp_bytes = (sb0 + sb1) / 2.0
+        b0 = sampling.walk_sample(graph, nodes, T, W, L, rng="philox", seed=42, call=0)
+        valid = ((b0.ids >= 0) & (b0.ids <= M - 1)).sum().item()
+        pool_bytes = valid * HID * 4 + n_loc * HID * 4 + n_loc * T * 8
+        lin_flops_step = 2.0 * n_loc * (F_IN * HID + LAYERS * (HID * HID + 2 * HID * HID) + HID * D)
+        enc_flops = 2.0 * D * nbits                              # per encoded row
+        kern = {}
+
+        def add(name, bound, per_launch_work, unit_peak):
+            if name not in ksum:
+                return
+            k = ksum[name]
+            ach = per_launch_work / (k["avg_ms"] * 1e-3)
+            kern[name] = {"launches_per_step": k["launches"] / a.steps, "avg_ms": round(k["avg_ms"], 4),
+                          "ms_per_step": round(k["ms"] / a.steps, 4), "bound": bound, "achieved": ach,
+                          "peak": unit_peak, "frac": ach / unit_peak}
+
+        add("ps_walk_sample", "hbm", samp_bytes, HBM_PEAK)
+        add("ps_importance_pool", "hbm", pool_bytes, HBM_PEAK)
+        if "ps_linear" in ksum:
+            add("ps_linear", "mfma", lin_flops_step / (ksum["ps_linear"]["launches"] / a.steps), MFMA_F32_PEAK)
+        if "ps_lsh_encode" in ksum:
+            rows = (n_loc + nq_local) / 2.0                      # two launches per step: index + queries
+            add("ps_lsh_encode", "mfma", enc_flops * rows, MFMA_F32_PEAK)
+        # Hamming scan: compulsory HBM bytes = one sweep of the local code table + queries + results
+        ham_bytes = n_loc * (nbits // 8) + nq * (nbits // 8) + nq * a.k * 12
+        add("ps_hamming_topk", "hbm", ham_bytes, HBM_PEAK)
+        dom = max(kern, key=lambda n: kern[n]["ms_per_step"])
+        kd = kern[dom]
+        roofline = {"kernel": dom, "bound": kd["bound"], "achieved": kd["achieved"] / (1e9 if kd["bound"] == "hbm" else 1e12),
+                    "peak": kd["peak"] / (1e9 if kd["bound"] == "hbm" else 1e12),
+                    "unit": "GB/s" if kd["bound"] == "hbm" else "TFLOP/s", "frac": kd["frac"], "traffic": None,
+                    "avg_launch_ms": kd["avg_ms"],
+                    "algorithmic_per_launch": samp_bytes if dom == "ps_walk_sample" else None,
+                    "steps_per_launch": (steps0 + steps1) / 2 if dom == "ps_walk_sample" else None}
+        for k in kern.values():
+            k["achieved"] = k["achieved"] / (1e9 if k["bound"] == "hbm" else 1e12)
+            k["peak"] = k["peak"] / (1e9 if k["bound"] == "hbm" else 1e12)
+            k["unit"] = "GB/s" if k["bound"] == "hbm" else "TFLOP/s"
+
+        out = {
+            "metric": "item embeddings/sec + top-K ANN queries/sec, ML-25M d=256, 1/2/4/8 GPU",
+            "value": value, "unit": "items/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64 cdf / f32 features / u32 codes", "data": "synthetic",
+            "config": {"workload": f"SYN-25M (ML-25M-shaped: U={U} M={M} R={R}), F=128 H=256 d={D}, 2 GCN layers, "
+                                   f"W=100 L=2 T={T}, LSH {nbits}-bit, {nq} queries K={a.k}, rng={a.rng}",
+                       "global_items": M, "queries": nq, "parallelism": f"item-shard x{world}"},
+            "embeddings_per_s": M / (phase_ms["embed"] / a.steps * 1e-3),
+            "index_items_per_s": M / (phase_ms["index"] / a.steps * 1e-3),
+            "queries_per_s": nq / (phase_ms["query"] / a.steps * 1e-3),
+            "phase_ms": {k: round(v / a.steps, 4) for k, v in phase_ms.items()},
+            "graph_build_s": round(t_graph, 3),
+            "roofline": roofline, "kernels": kern,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq)
+            out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and a.rng == "philox":
+            out["numpy_stream_mode"] = numpy_mode_probe(graph, model, pipe, x_loc, T, W, L, M, dev)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def numpy_mode_probe(graph, model, pipe, x_loc, T, W, L, M, dev):
+    """The numpy-compatible RNG mode (bit-exact with the reference's np.random stream), with the MT19937
+    stream generated on the device inside the timed region."""
+    from pinsage_hip import dense, sampling
+    from utils.random_walk import RandomWalkSampler
+    smp = RandomWalkSampler.from_graph(graph, L, W, rng="numpy")
+    nodes = torch.arange(M, dtype=torch.int64, device=dev)
+    ts = []
+    for _ in range(3):
+        np.random.seed(42)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            lists = []
+            for _l in range(2):
+                u = dense.mt19937_random_sample(M * W * L, dev)
+                b = sampling.walk_sample(graph, nodes, T, W, L, rng="numpy", uniforms=u)
+                lists.append((sampling.LazyNeighborList(b, "ids"), sampling.LazyNeighborList(b, "weights")))
+            model(x_loc, None, [l[0] for l in lists], [l[1] for l in lists])
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return {"embeddings_per_s": M / min(ts), "ms": min(ts) * 1e3,
+            "note": "np.random MT19937 stream generated on device (serial twist) + sampler + pooled forward"}
+
+
+def cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq):
+    """The CPU oracle (C port of the reference algorithm, pinned by the goldens) timed on this box's host
+    cores on a bounded sample of the same workload; dense layers use torch CPU (what the reference runs)."""
+    from oracle import c_oracle as co
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(threads, co.max_threads()))
+    torch.set_num_threads(threads)
+    cg = co.Graph.from_arrays(graph.rowptr.cpu().numpy(), graph.col.cpu().numpy(), graph.cdf.cpu().numpy())
+    S = min(a.cpu_sample, M)
+    rs = np.random.RandomState(0)
+    nodes = np.sort(rs.choice(M, size=S, replace=False))
+    t0 = time.perf_counter()
+    layers = []
+    for call in range(2):
+        ids, counts, nv, _, _, _ = co.walk_sample(cg, nodes, T, L, W, philox=(42, call), threads=threads)
+        layers.append((ids, counts, nv))
+    t_sample = time.perf_counter() - t0
+    P = {k: v.cpu() for k, v in params.items()}
+    xs = torch.randn(S, 128)
+    hfull = torch.randn(M, HID)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        h = torch.relu(torch.nn.functional.linear(xs, P["input_proj.weight"], P["input_proj.bias"]))
+        for i in range(2):
+            hn = torch.from_numpy(co.importance_pool(hfull.numpy(), layers[i][0], layers[i][1], layers[i][2], threads=threads))
+            hs = torch.nn.functional.linear(h, P[f"convs.{i}.lin_self.weight"], P[f"convs.{i}.lin_self.bias"])
+            h = torch.relu(torch.nn.functional.linear(torch.cat([hs, hn], 1), P[f"convs.{i}.lin_update.weight"],
+                                                      P[f"convs.{i}.lin_update.bias"]))
+            h = torch.nn.functional.normalize(h, dim=1)
+        e = torch.nn.functional.normalize(torch.nn.functional.linear(h, P["output_proj.weight"], P["output_proj.bias"]), dim=1)
+    t_dense = time.perf_counter() - t0
+    Ah = A.cpu()
+    t0 = time.perf_counter()
+    bits = (e @ Ah.t()) >= 0
+    codes_s = np.packbits(bits.numpy(), axis=1, bitorder="little")
+    t_enc = time.perf_counter() - t0
+    codes_all = pipe.codes.cpu().numpy()                      # the index built by the GPU pass (bit-exact codes)
+    Sq = min(2048, nq)
+    t0 = time.perf_counter()
+    co.hamming_topk(codes_all[:Sq], codes_all, a.k, threads=threads)
+    t_q = time.perf_counter() - t0
+    per_item = (t_sample + t_dense + t_enc) / S
+    step_s = per_item * M + t_q / Sq * nq
+    return {"value": M / step_s, "unit": "items/s", "cores": threads, "kind": "port",
+            "sample": f"{S} uniformly drawn start items (sampler x2 layers, pooling, dense, LSH encode) + {Sq} queries "
+                      f"over all {M} codes, scaled to the full step",
+            "seconds": {"sampler": round(t_sample, 3), "pool+dense": round(t_dense, 3), "encode": round(t_enc, 4),
+                        "query": round(t_q, 3)},
+            "embeddings_per_s": 1.0 / per_item, "queries_per_s": Sq / t_q}
+
+
+if __name__ == "__main__":
+    main()

@@ -77,10 +77,13 @@ int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf,
 
 /* _single_walk (utils/random_walk.py:52-83), batched: one walk of L steps per start node, one lane
  * per walk.  paths int32[B,L]: the visited nodes after the start (-1 once the walk hit a sink).
- * PS_RNG_STREAM: walk i, step s reads uniforms[uoff[i] + s]; PS_RNG_PHILOX: philox(seed; node, i, s, call). */
+ * PS_RNG_STREAM: walk i, step s reads uniforms[uoff[i] + s]; PS_RNG_PHILOX: philox(seed; node, w, s, call)
+ * with walk id w = i (walk_mod == 0) or i % walk_mod (replays walk w of ps_walk_sample when the start
+ * nodes are repeated W = walk_mod times). */
 int ps_walk_paths(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                   const int64_t *starts, int64_t B, int L, int rng_mode, const double *uniforms,
-                  const int64_t *uoff, uint64_t seed, uint32_t call, int32_t *paths, ps_stream_t stream);
+                  const int64_t *uoff, uint64_t seed, uint32_t call, int walk_mod, int32_t *paths,
+                  ps_stream_t stream);
 
 /* Offsets into the numpy stream: uoff[i] = W*L * #{j < i : outdeg(starts[j]) > 0};
  * total[0] = uniforms consumed by the whole batch. */

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void walk_sample_kernel(WalkArgs a) {
 
 __global__ void walk_paths_kernel(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                                   const int64_t *starts, int64_t B, int L, int rng_mode, const double *uniforms,
-                                  const int64_t *uoff, uint32_t k0, uint32_t k1, uint32_t call, int32_t *paths) {
+                                  const int64_t *uoff, uint32_t k0, uint32_t k1, uint32_t call, int walk_mod,
+                                  int32_t *paths) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = starts[i];
         int64_t cur = s;
@@ -201,7 +202,7 @@ __global__ void walk_paths_kernel(const int64_t *rowptr, const int32_t *col, con
                 } else {
                     double u;
                     if (rng_mode == PS_RNG_STREAM) u = uniforms[ubase + st];
-                    else u = philox_uniform(k0, k1, (uint32_t)s, (uint32_t)i, (uint32_t)st, call);
+                    else u = philox_uniform(k0, k1, (uint32_t)s, (uint32_t)(walk_mod > 0 ? i % walk_mod : i), (uint32_t)st, call);
                     int64_t l = lo, h = hi;
                     while (l < h) {
                         const int64_t mid = l + ((h - l) >> 1);
@@ -306,7 +307,8 @@ extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const d
 
 extern "C" int ps_walk_paths(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                              const int64_t *starts, int64_t B, int L, int rng_mode, const double *uniforms,
-                             const int64_t *uoff, uint64_t seed, uint32_t call, int32_t *paths, ps_stream_t stream) {
+                             const int64_t *uoff, uint64_t seed, uint32_t call, int walk_mod, int32_t *paths,
+                             ps_stream_t stream) {
     if (B < 0 || L <= 0) return PS_EINVAL;
     if (B == 0) return PS_OK;
     if (!rowptr || !col || !cdf || !starts || !paths) return PS_EINVAL;
@@ -315,7 +317,7 @@ extern "C" int ps_walk_paths(const int64_t *rowptr, const int32_t *col, const do
     int64_t grid = ps_cdiv(B, 256);
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(walk_paths_kernel, dim3((unsigned)grid), dim3(256), 0, ps_stream(stream), rowptr, col, cdf, V,
-                       starts, B, L, rng_mode, uniforms, uoff, (uint32_t)seed, (uint32_t)(seed >> 32), call, paths);
+                       starts, B, L, rng_mode, uniforms, uoff, (uint32_t)seed, (uint32_t)(seed >> 32), call, walk_mod, paths);
     PS_CHECK_LAUNCH();
     return PS_OK;
 }

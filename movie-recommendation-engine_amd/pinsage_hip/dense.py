@@ -50,9 +50,9 @@ def linear(x, W, b=None, x2=None, W2=None, relu=False, l2norm=False):
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     flags = (nv.PS_RELU if relu else 0) | (nv.PS_L2NORM if l2norm else 0)
     with torch.cuda.device(x.device):
-        nv.check(nv.lib().ps_linear(nv.ptr(x), nv.i64(M), nv.i32(K), _ptr_view(Wk), nv.i32(ldw), nv.ptr(b), nv.i32(N),
+        nv.call("ps_linear", nv.ptr(x), nv.i64(M), nv.i32(K), _ptr_view(Wk), nv.i32(ldw), nv.ptr(b), nv.i32(N),
                                     nv.ptr(x2), nv.i32(K2), _ptr_view(W2k), nv.i32(ldw2), nv.i32(flags), nv.ptr(y),
-                                    nv.stream()), "ps_linear")
+                                    nv.stream())
     return y
 
 
@@ -66,8 +66,8 @@ def lsh_encode(x, A):
         raise ValueError("projection matrix must be [nbits, dim]")
     codes = torch.empty((n, nbits // 8), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        nv.check(nv.lib().ps_lsh_encode(nv.ptr(x), nv.i64(n), nv.i32(d), nv.ptr(A), nv.i32(nbits), nv.ptr(codes),
-                                        nv.stream()), "ps_lsh_encode")
+        nv.call("ps_lsh_encode", nv.ptr(x), nv.i64(n), nv.i32(d), nv.ptr(A), nv.i32(nbits), nv.ptr(codes),
+                                        nv.stream())
     return codes
 
 
@@ -83,9 +83,9 @@ def hamming_topk(qcodes, codes, k, id_offset=0):
     wsb = int(L.ps_hamming_topk_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(cs), nv.i32(k)))
     ws = torch.empty(wsb, dtype=torch.uint8, device=qcodes.device)
     with torch.cuda.device(qcodes.device):
-        nv.check(L.ps_hamming_topk(nv.ptr(qcodes), nv.i64(nq), nv.ptr(codes) if N else nv.C.c_void_p(0), nv.i64(N),
+        nv.call("ps_hamming_topk", nv.ptr(qcodes), nv.i64(nq), nv.ptr(codes) if N else nv.C.c_void_p(0), nv.i64(N),
                                    nv.i32(cs), nv.i32(k), nv.i64(id_offset), nv.ptr(dist), nv.ptr(ids), nv.ptr(ws),
-                                   nv.C.c_size_t(wsb), nv.stream()), "ps_hamming_topk")
+                                   nv.C.c_size_t(wsb), nv.stream())
     return dist, ids
 
 
@@ -97,8 +97,8 @@ def topk_merge(dist_in, ids_in):
     dist = torch.empty((nq, k), dtype=torch.int32, device=dist_in.device)
     ids = torch.empty((nq, k), dtype=torch.int64, device=dist_in.device)
     with torch.cuda.device(dist_in.device):
-        nv.check(nv.lib().ps_topk_merge(nv.ptr(dist_in), nv.ptr(ids_in), nv.i32(P), nv.i64(nq), nv.i32(k), nv.ptr(dist),
-                                        nv.ptr(ids), nv.stream()), "ps_topk_merge")
+        nv.call("ps_topk_merge", nv.ptr(dist_in), nv.ptr(ids_in), nv.i32(P), nv.i64(nq), nv.i32(k), nv.ptr(dist),
+                                        nv.ptr(ids), nv.stream())
     return dist, ids
 
 
@@ -114,9 +114,9 @@ def dot_topk(E, qidx, k, exclude_self=True):
     wsb = int(L.ps_dot_topk_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(D), nv.i32(k)))
     ws = torch.empty(wsb, dtype=torch.uint8, device=E.device)
     with torch.cuda.device(E.device):
-        nv.check(L.ps_dot_topk(nv.ptr(E), nv.i64(N), nv.i32(D), nv.ptr(qidx), nv.i64(nq), nv.i32(k),
+        nv.call("ps_dot_topk", nv.ptr(E), nv.i64(N), nv.i32(D), nv.ptr(qidx), nv.i64(nq), nv.i32(k),
                                nv.i32(int(exclude_self)), nv.ptr(vals), nv.ptr(ids), nv.ptr(ws), nv.C.c_size_t(wsb),
-                               nv.stream()), "ps_dot_topk")
+                               nv.stream())
     return vals, ids
 
 
@@ -134,9 +134,8 @@ def mt19937_random_sample(n, device):
     pos_out = torch.empty(1, dtype=torch.int32, device=dev)
     out = torch.empty(int(n), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        nv.check(nv.lib().ps_mt19937_random_sample(nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(n)), nv.ptr(out),
-                                                   nv.ptr(st_out), nv.ptr(pos_out), nv.stream()),
-                 "ps_mt19937_random_sample")
+        nv.call("ps_mt19937_random_sample", nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(n)), nv.ptr(out),
+                                                   nv.ptr(st_out), nv.ptr(pos_out), nv.stream())
     new_key = st_out.cpu().numpy().view(np.uint32)
     np.random.set_state((name, new_key, int(pos_out.item()), has_gauss, cached))
     return out

@@ -43,14 +43,12 @@ class DeviceGraph:
         ws_bytes = int(L.ps_csr_build_workspace_bytes(nv.i64(E), nv.i64(V)))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            nv.check(L.ps_csr_build(nv.ptr(src), nv.ptr(dst), nv.ptr(w), nv.i64(E), nv.i64(V), nv.ptr(self.rowptr),
-                                    nv.ptr(self.col), nv.ptr(wsorted), nv.ptr(ws), nv.C.c_size_t(ws_bytes), nv.stream()),
-                     "ps_csr_build")
-            nv.check(L.ps_cdf_build(nv.ptr(self.rowptr), nv.ptr(wsorted), nv.i64(V), nv.ptr(self.cdf), nv.stream()),
-                     "ps_cdf_build")
+            nv.call("ps_csr_build", nv.ptr(src), nv.ptr(dst), nv.ptr(w), nv.i64(E), nv.i64(V), nv.ptr(self.rowptr),
+                                    nv.ptr(self.col), nv.ptr(wsorted), nv.ptr(ws), nv.C.c_size_t(ws_bytes), nv.stream())
+            nv.call("ps_cdf_build", nv.ptr(self.rowptr), nv.ptr(wsorted), nv.i64(V), nv.ptr(self.cdf), nv.stream())
             flags = torch.zeros(2, dtype=torch.int64, device=dev)
-            nv.check(L.ps_graph_stats(nv.ptr(self.rowptr), nv.ptr(self.col), nv.i64(E), nv.i64(V), nv.ptr(flags),
-                                      nv.stream()), "ps_graph_stats")
+            nv.call("ps_graph_stats", nv.ptr(self.rowptr), nv.ptr(self.col), nv.i64(E), nv.i64(V), nv.ptr(flags),
+                                      nv.stream())
             f = flags.tolist()
         self.has_reachable_sink = bool(f[0])
         self.max_degree = int(f[1])

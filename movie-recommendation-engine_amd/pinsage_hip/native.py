@@ -59,6 +59,47 @@ def check(rc: int, what: str):
         raise NativeError(f"{what}: {lib().ps_error_string(rc).decode()} (code {rc})")
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing (events are recorded on the stream the kernels are
+    launched on, torch's current stream; nothing synchronises until `summary`)."""
+
+    def __init__(self):
+        self.events = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.events:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0})
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+        for d in out.values():
+            d["avg_ms"] = d["ms"] / d["launches"]
+        return out
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+def call(name, *args):
+    """Invoke one C-ABI entry point and raise on a non-zero status."""
+    fn = getattr(lib(), name)
+    if _timer is None:
+        rc = fn(*args)
+    else:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        _timer.events.append((name, a, b))
+    check(rc, name)
+
+
 def ptr(t):
     """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
     if t is None:

@@ -128,9 +128,8 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
                     "reference's RNG consumption is data dependent -- use rng='philox'")
             uoff = torch.empty(B, dtype=torch.int64, device=dev)
             total = torch.empty(1, dtype=torch.int64, device=dev)
-            nv.check(L_.ps_uniform_offsets(nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(starts), nv.i64(B),
-                                           nv.i32(W), nv.i32(L), nv.ptr(uoff), nv.ptr(total), nv.stream()),
-                     "ps_uniform_offsets")
+            nv.call("ps_uniform_offsets", nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(starts), nv.i64(B),
+                                           nv.i32(W), nv.i32(L), nv.ptr(uoff), nv.ptr(total), nv.stream())
             if uniforms is None:
                 n = int(total.item())
                 uniforms = draw_numpy_uniforms(n, dev)
@@ -139,14 +138,14 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
             uoff, uniforms, mode = None, None, nv.PS_RNG_PHILOX
         else:
             raise ValueError("rng must be 'numpy' or 'philox'")
-        nv.check(L_.ps_walk_sample(nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
+        nv.call("ps_walk_sample", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
                                    nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T), nv.i32(mode),
                                    nv.ptr(uniforms), nv.ptr(uoff), nv.u64(seed & (2 ** 64 - 1)), nv.u32(call),
-                                   nv.ptr(ids), nv.ptr(counts), nv.ptr(nvalid), nv.stream()), "ps_walk_sample")
+                                   nv.ptr(ids), nv.ptr(counts), nv.ptr(nvalid), nv.stream())
     return NeighborBatch(ids, counts, nvalid)
 
 
-def walk_paths(graph, starts, L, rng="numpy", seed=0, call=0):
+def walk_paths(graph, starts, L, rng="numpy", seed=0, call=0, walk_mod=0):
     """One walk per start node: int32[B,L] visited nodes (-1 after a sink)."""
     dev = graph.device
     st = _nodes_tensor(starts, dev)
@@ -161,15 +160,15 @@ def walk_paths(graph, starts, L, rng="numpy", seed=0, call=0):
                 raise NotImplementedError("rng='numpy' needs a graph without reachable sinks; use rng='philox'")
             uoff = torch.empty(B, dtype=torch.int64, device=dev)
             total = torch.empty(1, dtype=torch.int64, device=dev)
-            nv.check(L_.ps_uniform_offsets(nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(st), nv.i64(B), nv.i32(1),
-                                           nv.i32(L), nv.ptr(uoff), nv.ptr(total), nv.stream()), "ps_uniform_offsets")
+            nv.call("ps_uniform_offsets", nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(st), nv.i64(B), nv.i32(1),
+                                           nv.i32(L), nv.ptr(uoff), nv.ptr(total), nv.stream())
             uniforms = draw_numpy_uniforms(int(total.item()), dev)
             mode = nv.PS_RNG_STREAM
         else:
             uoff, uniforms, mode = None, None, nv.PS_RNG_PHILOX
-        nv.check(L_.ps_walk_paths(nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
+        nv.call("ps_walk_paths", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
                                   nv.ptr(st), nv.i64(B), nv.i32(L), nv.i32(mode), nv.ptr(uniforms), nv.ptr(uoff),
-                                  nv.u64(seed & (2 ** 64 - 1)), nv.u32(call), nv.ptr(paths), nv.stream()), "ps_walk_paths")
+                                  nv.u64(seed & (2 ** 64 - 1)), nv.u32(call), nv.i32(walk_mod), nv.ptr(paths), nv.stream())
     return paths
 
 
@@ -187,7 +186,7 @@ def importance_pool(x, batch: NeighborBatch = None, ids=None, counts=None, wts=N
     if max_idx is None:
         max_idx = N - 1
     with torch.cuda.device(x.device):
-        nv.check(nv.lib().ps_importance_pool(nv.ptr(x), nv.i64(N), nv.i32(H), nv.ptr(ids), nv.ptr(counts), nv.ptr(wts),
+        nv.call("ps_importance_pool", nv.ptr(x), nv.i64(N), nv.i32(H), nv.ptr(ids), nv.ptr(counts), nv.ptr(wts),
                                              nv.ptr(nvalid), nv.i64(B), nv.i32(T), nv.i64(max_idx), nv.i32(int(renorm)),
-                                             nv.ptr(out), nv.stream()), "ps_importance_pool")
+                                             nv.ptr(out), nv.stream())
     return out

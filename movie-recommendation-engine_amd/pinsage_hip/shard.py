@@ -1,0 +1,121 @@
+"""Item-range sharding of the PinSage hot path over the GPUs of one node (one process per GPU,
+torch.distributed; backend "nccl" is RCCL over xGMI).
+
+The reference is single-process (no distributed code), so this layer is new.  The item
+catalogue is cut into `world` contiguous id ranges; the CSR + CDF graph is replicated (walks leave a
+shard after one step).  Per GCN layer there is ONE exchange: the all-gather of the hidden rows
+h^(l) (layer l+1's importance pooling gathers arbitrary global rows, model/pinsage.py:232).  Neighbour
+sampling needs no communication (Philox counters are keyed by the global node id, so results do not
+depend on the shard count).  LSH: every rank encodes and keeps its code shard; query codes are
+all-gathered (tiny), every rank scans its shard, the [nq, k] candidates are all-gathered and merged with
+the same (distance, id) order -> identical to the 1-GPU answer on every rank.
+
+`ops` is the compute backend: HipOps (libpinsage_hip.so) in production; tests inject a CPU checker to
+exercise the orchestration under gloo.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import dense, sampling
+
+
+def shard_range(M, rank, world):
+    chunk = (M + world - 1) // world
+    lo = min(rank * chunk, M)
+    return lo, min(lo + chunk, M), chunk
+
+
+def _backend(group):
+    return dist.get_backend(group) if dist.is_initialized() else None
+
+
+def all_gather_rows(t, chunk, group=None):
+    """[n_local, ...] (n_local <= chunk) -> [world * chunk, ...]; rank r's rows start at r * chunk."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    world = dist.get_world_size(group)
+    pad = torch.zeros((chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.size(0)] = t
+    stage_cpu = _backend(group) == "gloo" and pad.is_cuda       # gloo has no CUDA all_gather
+    src = pad.cpu() if stage_cpu else pad
+    out = torch.empty((world * chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src.contiguous(), group=group)
+    return out.to(t.device) if stage_cpu else out
+
+
+class HipOps:
+    """The production backend: thin names over the C-ABI wrappers."""
+
+    def sample(self, sampler, nodes, T):
+        return sampler.sample_batch(nodes, T)
+
+    def pool(self, h_full, batch, max_idx):
+        return sampling.importance_pool(h_full, batch, max_idx=max_idx)
+
+    def linear(self, x, W, b, x2=None, W2=None, relu=False, l2norm=False):
+        return dense.linear(x, W, b, x2=x2, W2=W2, relu=relu, l2norm=l2norm)
+
+    def lsh_encode(self, x, A):
+        return dense.lsh_encode(x, A)
+
+    def hamming_topk(self, q, codes, k, id_offset):
+        return dense.hamming_topk(q, codes, k, id_offset=id_offset)
+
+    def topk_merge(self, d, i):
+        return dense.topk_merge(d, i)
+
+
+class ShardedPinSage:
+    """get_embeddings + LSH build/search over `world` item shards."""
+
+    def __init__(self, params, num_layers, sampler, num_items, ops=None, group=None):
+        self.P = params                   # state_dict tensors (replicated), on the compute device
+        self.num_layers = num_layers
+        self.sampler = sampler
+        self.M = int(num_items)
+        self.ops = ops if ops is not None else HipOps()
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.lo, self.hi, self.chunk = shard_range(self.M, self.rank, self.world)
+
+    # -- embeddings: PinSage.get_embeddings (model/pinsage.py:253-280) for the local item range ------
+    def embed(self, x_local, T):
+        ops, P = self.ops, self.P
+        dev = x_local.device
+        nodes = torch.arange(self.lo, self.hi, dtype=torch.int64, device=dev)
+        # fresh neighbour samples per layer, drawn in the reference's order (:271-275); no communication
+        batches = [ops.sample(self.sampler, nodes, T) for _ in range(self.num_layers)]
+        h = ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
+        for i in range(self.num_layers):
+            h_full = all_gather_rows(h, self.chunk, self.group)          # the per-layer exchange
+            h_neigh = ops.pool(h_full, batches[i], self.M - 1)
+            H = h.size(1)
+            h_self = ops.linear(h, P[f"convs.{i}.lin_self.weight"], P[f"convs.{i}.lin_self.bias"])
+            Wu = P[f"convs.{i}.lin_update.weight"]
+            h = ops.linear(h_self, Wu[:, :H], P[f"convs.{i}.lin_update.bias"], x2=h_neigh, W2=Wu[:, H:],
+                           relu=True, l2norm=True)
+        return ops.linear(h, P["output_proj.weight"], P["output_proj.bias"], l2norm=True)
+
+    # -- LSH: LSHIndex.build / .search (utils/nearest_neighbors.py:28-68) over code shards -------------
+    def build_index(self, emb_local, A):
+        self.A = A
+        self.codes = self.ops.lsh_encode(emb_local, A)
+        return self.codes
+
+    def search(self, q_local, k):
+        """q_local: this rank's query embeddings [nq_local, D] (every rank contributes the same count).
+        Returns (dist int32[nq, k], ids int64[nq, k]) for ALL queries, rank-major, on every rank."""
+        ops = self.ops
+        qc = ops.lsh_encode(q_local, self.A)
+        nq_local = qc.size(0)
+        qc_all = all_gather_rows(qc, nq_local, self.group)
+        d, i = ops.hamming_topk(qc_all, self.codes, k, self.lo)
+        if self.world == 1:
+            return d, i
+        nq = qc_all.size(0)
+        d_all = all_gather_rows(d.reshape(1, nq, k), 1, self.group)
+        i_all = all_gather_rows(i.reshape(1, nq, k), 1, self.group)
+        return ops.topk_merge(d_all, i_all)

@@ -36,6 +36,16 @@ class RandomWalkSampler:
     def _prepare_adjacency_list(self, device=None):
         self.graph = DeviceGraph(self.edge_index, self.edge_weights, device=device)
 
+    @classmethod
+    def from_graph(cls, graph, walk_length=2, num_walks=100, rng="numpy", seed=0):
+        """A sampler over an already built DeviceGraph (shares the CSR/CDF in HBM)."""
+        self = cls.__new__(cls)
+        self.edge_index = self.edge_weights = None
+        self.walk_length, self.num_walks, self.p, self.q = walk_length, num_walks, 1.0, 1.0
+        self.rng, self.seed, self._calls, self._adj_list = rng, int(seed), 0, None
+        self.graph = graph
+        return self
+
     @property
     def adj_list(self):
         """The reference's python adjacency list (utils/random_walk.py:39-50), built on demand."""

@@ -70,6 +70,17 @@ class Graph:
         _check(lib().orc_cdf_build(_p(self.rowptr), _p(self.w), C.c_int64(V), _p(self.cdf), C.c_int(threads)),
                "orc_cdf_build")
 
+    @classmethod
+    def from_arrays(cls, rowptr, col, cdf):
+        """Wrap an existing CSR + CDF (e.g. copied back from the device) without rebuilding."""
+        self = cls.__new__(cls)
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        self.col = np.ascontiguousarray(col, dtype=np.int32)
+        self.cdf = np.ascontiguousarray(cdf, dtype=np.float64)
+        self.w = None
+        self.V, self.E = self.rowptr.shape[0] - 1, self.col.shape[0]
+        return self
+
     def uniform_offsets(self, nodes, W, L):
         """Offsets into the numpy stream per start node, valid on sink-free graphs."""
         nodes = np.asarray(nodes, dtype=np.int64)

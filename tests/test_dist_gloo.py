@@ -1,0 +1,144 @@
+"""The N>1 orchestration (item-range shards, per-layer all-gather of hidden rows, all-gather +
+merge of top-k candidates) under gloo with world_size 2 on CPU.  The compute backend is swapped for
+the CPU oracle (allowed: tests only), so what is checked here is that the sharded pipeline's answer is
+identical to the single-shard one -- ids / codes / neighbour ids bit-exact, embeddings to 1e-6."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import bipartite_graph
+
+M, U, T, W, L, K = 101, 60, 10, 50, 2, 7      # odd M: uneven shards
+
+
+class _Batch:
+    def __init__(self, ids, counts, nvalid):
+        self.ids, self.counts, self.nvalid = ids, counts, nvalid
+
+
+class _Sampler:
+    def __init__(self, cg, seed):
+        self.cg, self.seed, self._calls = cg, seed, 0
+
+
+class OracleOps:
+    def sample(self, sampler, nodes, T_):
+        from oracle import c_oracle as co
+        call = sampler._calls
+        sampler._calls += 1
+        ids, counts, nv, _, _, _ = co.walk_sample(sampler.cg, nodes.numpy(), T_, L, W, philox=(sampler.seed, call))
+        return _Batch(torch.from_numpy(ids), torch.from_numpy(counts), torch.from_numpy(nv))
+
+    def pool(self, h_full, batch, max_idx):
+        from oracle import c_oracle as co
+        return torch.from_numpy(co.importance_pool(h_full[: max_idx + 1].numpy(), batch.ids.numpy(), batch.counts.numpy(),
+                                                   batch.nvalid.numpy()))
+
+    def linear(self, x, Wt, b, x2=None, W2=None, relu=False, l2norm=False):
+        from oracle import c_oracle as co
+        return torch.from_numpy(co.linear(x.numpy(), Wt.contiguous().numpy(), None if b is None else b.numpy(),
+                                          x2=None if x2 is None else x2.numpy(),
+                                          W2=None if W2 is None else W2.contiguous().numpy(), relu=relu, l2norm=l2norm))
+
+    def lsh_encode(self, x, A):
+        from oracle import c_oracle as co
+        return torch.from_numpy(co.lsh_encode(x.numpy(), A.numpy()))
+
+    def hamming_topk(self, q, codes, k, id_offset):
+        from oracle import c_oracle as co
+        d, i = co.hamming_topk(q.numpy(), codes.numpy(), k, id_offset=id_offset)
+        d = np.where(i < 0, 2147483647, d).astype(np.int32)
+        return torch.from_numpy(d), torch.from_numpy(i)
+
+    def topk_merge(self, d, i):
+        P, nq, k = d.shape
+        dd = d.permute(1, 0, 2).reshape(nq, P * k).numpy().astype(np.int64)
+        ii = i.permute(1, 0, 2).reshape(nq, P * k).numpy()
+        od = np.empty((nq, k), dtype=np.int32)
+        oi = np.empty((nq, k), dtype=np.int64)
+        for r in range(nq):
+            key_i = np.where(ii[r] < 0, np.iinfo(np.int64).max, ii[r])
+            order = np.lexsort((key_i, dd[r]))[:k]
+            od[r], oi[r] = dd[r][order], ii[r][order]
+        return torch.from_numpy(od), torch.from_numpy(oi)
+
+
+def _setup():
+    from oracle import c_oracle as co
+    from oracle import pinsage_oracle as orc
+    ei, ew = bipartite_graph(M, U, 3000, 21, "half")
+    cg = co.Graph(ei, ew)
+    torch.manual_seed(3)
+    from model.pinsage import PinSage
+    params = {k: v.detach() for k, v in PinSage(12, 24, 16, 2).state_dict().items()}
+    x = torch.randn(M, 12)
+    A = torch.from_numpy(orc.lsh_rotation_matrix(16, 32))
+    return cg, params, x, A
+
+
+def _run(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pinsage_hip.shard import ShardedPinSage, all_gather_rows
+        cg, params, x, A = _setup()
+        pipe = ShardedPinSage(params, 2, _Sampler(cg, 77), M, ops=OracleOps())
+        emb = pipe.embed(x[pipe.lo:pipe.hi], T)
+        codes = pipe.build_index(emb, A)
+        nq_local = 8
+        d, i = pipe.search(emb[:nq_local], K)
+        emb_all = all_gather_rows(emb, pipe.chunk)[:M]
+        codes_all = all_gather_rows(codes, pipe.chunk)[:M]
+        if rank == 0:
+            torch.save({"emb": emb_all, "codes": codes_all, "d": d, "i": i, "chunk": pipe.chunk}, out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_pipeline_equals_single(tmp_path):
+    from oracle import c_oracle as co
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single-shard reference, straight from the oracle
+    cg, params, x, A = _setup()
+    layers = []
+    for call in range(2):
+        ids, counts, nv, _, _, _ = co.walk_sample(cg, np.arange(M), T, L, W, philox=(77, call))
+        layers.append((ids, counts, nv))
+    ref = co.pinsage_forward({k: v.numpy() for k, v in params.items()}, x.numpy(), layers)
+    np.testing.assert_allclose(got["emb"].numpy(), ref, rtol=1e-6, atol=1e-7)
+    ref_codes = co.lsh_encode(got["emb"].numpy(), A.numpy())
+    assert np.array_equal(got["codes"].numpy(), ref_codes)
+    chunk = got["chunk"]
+    qrows = np.concatenate([np.arange(8), chunk + np.arange(8)])          # rank-major query order
+    rd, ri = co.hamming_topk(ref_codes[qrows], ref_codes, K)
+    assert np.array_equal(got["i"].numpy(), ri)
+    assert np.array_equal(got["d"].numpy(), rd.astype(np.int32))
+
+
+def test_shard_range_covers_catalogue():
+    from pinsage_hip.shard import shard_range
+    for m in (1, 7, 8, 59047, 100):
+        for w in (1, 2, 4, 8):
+            rows = []
+            for r in range(w):
+                lo, hi, chunk = shard_range(m, r, w)
+                assert hi - lo <= chunk and lo == min(r * chunk, m)
+                rows += list(range(lo, hi))
+            assert rows == list(range(m))

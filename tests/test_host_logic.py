@@ -1,0 +1,104 @@
+"""Host-side logic that needs no GPU: list <-> padded conversion with the reference's filtering
+rules, the lazy list view, the surface (signatures / parameter names), MLP branch + autograd."""
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_lists_to_padded_follows_reference_filter():
+    from model.pinsage import _lists_to_padded
+    nbrs = [3, [1, 2, 40], [], [5, 6, 7], [np.int64(9), 2.5, "a", -1]]
+    wts = [0.3, [0.5, 0.25, 0.25], [], [0.7], [0.1, 0.2, 0.3, 0.4]]
+    ids, w, nv = _lists_to_padded(30, nbrs, wts)
+    assert nv.tolist() == [1, 2, 0, 3, 2]
+    assert ids[0, 0] == 3 and w[0, 0] == 1.0                     # scalar int -> weight 1.0 (pinsage.py:110-112)
+    assert ids[1, :2].tolist() == [1, 2]                         # 40 > max_idx dropped with its weight
+    assert w[3, :3].tolist() == [np.float32(0.7), 1.0, 1.0]      # missing weights -> 1.0 (:126-129)
+    assert ids[4, :2].tolist() == [9, 29] and w[4, 1] == np.float32(0.4)   # non-int entries skipped; -1 wraps
+    with pytest.raises(IndexError):
+        _lists_to_padded(30, [[-31]], [[1.0]])
+
+
+def test_lazy_neighbor_list_is_a_list():
+    from pinsage_hip.sampling import LazyNeighborList, NeighborBatch
+    ids = torch.tensor([[4, 9, -1], [7, -1, -1], [-1, -1, -1]], dtype=torch.int32)
+    cnt = torch.tensor([[3, 1, 0], [5, 0, 0], [0, 0, 0]], dtype=torch.int32)
+    b = NeighborBatch(ids, cnt, torch.tensor([2, 1, 0], dtype=torch.int32))
+    nb, wt = LazyNeighborList(b, "ids"), LazyNeighborList(b, "weights")
+    assert isinstance(nb, list) and len(nb) == 3 and not nb._done
+    assert [list(map(int, r)) for r in nb] == [[4, 9], [7], []]
+    assert all(isinstance(v, np.integer) for v in nb[0])
+    assert wt[0] == [3 / 4, 1 / 4] and wt[1] == [1.0] and wt[2] == []
+    assert [len(a) for a, _ in zip(nb, wt)] == [2, 1, 0]
+
+
+def test_surface_signatures_match_reference():
+    from model.pinsage import PinSage, ImportancePooling, GraphConv
+    from model import aggregators as A
+    from utils.random_walk import RandomWalkSampler
+    from utils import nearest_neighbors as nn_
+    assert list(inspect.signature(RandomWalkSampler.__init__).parameters)[:7] == \
+        ["self", "edge_index", "edge_weights", "walk_length", "num_walks", "p", "q"]
+    assert list(inspect.signature(RandomWalkSampler.batch_sample_neighbors).parameters) == ["self", "nodes", "num_neighbors"]
+    assert list(inspect.signature(RandomWalkSampler.sample_neighbors).parameters) == ["self", "node_idx", "num_neighbors"]
+    for name in ("_single_walk", "compute_ppr_matrix", "precompute_top_neighbors"):
+        assert hasattr(RandomWalkSampler, name)
+    assert list(inspect.signature(PinSage.forward).parameters) == \
+        ["self", "x", "edge_index", "sampled_neighbors", "importance_weights"]
+    assert list(inspect.signature(PinSage.get_embeddings).parameters) == ["self", "x", "random_walk_sampler", "num_neighbors"]
+    assert list(inspect.signature(ImportancePooling.forward).parameters) == ["self", "x", "neighbors", "weights"]
+    assert list(inspect.signature(GraphConv.forward).parameters) == ["self", "x", "edge_index", "edge_weight", "importance_weights"]
+    m = PinSage(128, 256, 128, 2)
+    assert sorted(m.state_dict()) == sorted(
+        ["input_proj.weight", "input_proj.bias", "output_proj.weight", "output_proj.bias"] +
+        [f"convs.{i}.{l}.{p}" for i in range(2) for l in ("lin_self", "lin_neigh", "lin_update") for p in ("weight", "bias")])
+    assert m.convs[0].lin_update.weight.shape == (256, 512) and m.num_layers == 2
+    assert sum(p.numel() for p in m.parameters()) == 591744       # the shipped checkpoint's parameter count
+    assert list(inspect.signature(nn_.LSHIndex.__init__).parameters) == ["self", "dim", "num_bits", "num_tables"]
+    for cls, keys in ((A.ImportanceAggregator(8, 6), {"transform.weight", "transform.bias", "norm.weight", "norm.bias"}),
+                      (A.AttentionAggregator(8), {"attention.0.weight", "attention.0.bias", "attention.2.weight", "attention.2.bias"}),
+                      (A.MaxPoolingAggregator(8, 6), {"mlp.0.weight", "mlp.0.bias"})):
+        assert set(cls.state_dict()) == keys
+
+
+def test_mlp_and_edge_branches_on_cpu(golden):
+    """The MLP branch (what train.py trains, model/pinsage.py:205-214) is plain torch and must work
+    and be differentiable anywhere; the edge_index branch is GraphConv without torch_geometric."""
+    from model.pinsage import PinSage
+    g = golden
+    m = PinSage(16, 32, 8, num_layers=2)
+    m.load_state_dict({k[len("g3_param_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("g3_param_")})
+    x = torch.from_numpy(g["g3_x"])
+    e = m(x)
+    np.testing.assert_allclose(e.detach().numpy(), g["g3_e_mlp"], rtol=1e-5, atol=1e-6)
+    loss = -torch.mean(torch.sum(e * e.detach(), dim=1))          # train.py:77-78 shape
+    loss.backward()
+    assert m.output_proj.weight.grad is not None and m.convs[0].lin_neigh.weight.grad is None
+    # edge branch: dense reference  x_neigh[dst] += lin_neigh(h)[src]
+    ei = torch.tensor([[0, 1, 2, 2], [1, 2, 0, 1]])
+    with torch.no_grad():
+        out = m(x[:3], edge_index=ei)
+        h = torch.relu(m.input_proj(x[:3]))
+        for conv in m.convs:
+            ln = conv.lin_neigh(h)
+            agg = torch.zeros_like(ln)
+            for s, d in ei.t().tolist():
+                agg[d] += ln[s]
+            h = torch.nn.functional.normalize(torch.relu(conv.lin_update(torch.cat([conv.lin_self(h), agg], 1))), dim=1)
+        ref = torch.nn.functional.normalize(m.output_proj(h), dim=1)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_lsh_rotation_matrix_properties():
+    from utils.nearest_neighbors import lsh_rotation_matrix
+    from oracle import pinsage_oracle as orc
+    for d, nbits in ((16, 16), (32, 16), (16, 64)):
+        A = lsh_rotation_matrix(d, nbits)
+        assert A.shape == (nbits, d) and A.dtype == np.float32
+        assert np.array_equal(A, orc.lsh_rotation_matrix(d, nbits))
+        if nbits <= d:
+            np.testing.assert_allclose(A @ A.T, np.eye(nbits), atol=1e-5)
+        else:
+            np.testing.assert_allclose(A.T @ A, np.eye(d), atol=1e-5)   # tight frame
