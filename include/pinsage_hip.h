@@ -55,6 +55,14 @@ int ps_csr_build(const int64_t *src, const int64_t *dst, const float *w, int64_t
  * same operation order (bit-exact).  cdf double[E]. */
 int ps_cdf_build(const int64_t *rowptr, const double *wsorted, int64_t V, double *cdf, ps_stream_t stream);
 
+/* Acceleration records for the walk kernels (exact, results unchanged):
+ *  nodeinfo uint32[2V] : (row start, out-degree) of every node in one 8-byte record;
+ *  guide    int32[E]   : guide[lo_v + j] = #{k : cdf_v[k] <= (j-1)/deg_v}, j = 0..deg_v-1 -- a bucket table
+ *  for the inverse-CDF lookup: searchsorted(cdf_v, u, 'right') starts at guide[lo_v + floor(u*deg_v)] and
+ *  scans forward (usually 1-2 entries) instead of probing log2(deg) cache lines. */
+int ps_guide_build(const int64_t *rowptr, const double *cdf, int64_t V, uint32_t *nodeinfo, int32_t *guide,
+                   ps_stream_t stream);
+
 /* flags[0] = 1 iff some edge points at a node with out-degree 0 (a reachable sink: the
  * reference's walk then breaks early, utils/random_walk.py:68-69, and its RNG consumption
  * becomes data dependent); flags[1] = max out-degree.  flags int64[2]. */
@@ -68,11 +76,13 @@ int ps_graph_stats(const int64_t *rowptr, const int32_t *col, int64_t E, int64_t
  *   (uoff int64[B]; the numpy call order on a graph without reachable sinks).
  * rng_mode PS_RNG_PHILOX: uniforms/uoff ignored; u = philox(seed; node, w, s, call).
  * Out: ids int32[B,T] (-1 pad), counts int32[B,T] (0 pad), nvalid int32[B].
- * The reference's weights are counts[i,j] / sum_j counts[i,:nvalid[i]] (:113-115). */
+ * The reference's weights are counts[i,j] / sum_j counts[i,:nvalid[i]] (:113-115).
+ * nodeinfo/guide (both or neither; from ps_guide_build) select the bucket-table lookup; NULL = plain
+ * binary search over the CDF row. */
 int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                    const int64_t *starts, int64_t B, int W, int L, int T,
                    int rng_mode, const double *uniforms, const int64_t *uoff,
-                   uint64_t seed, uint32_t call,
+                   uint64_t seed, uint32_t call, const uint32_t *nodeinfo, const int32_t *guide,
                    int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream);
 
 /* _single_walk (utils/random_walk.py:52-83), batched: one walk of L steps per start node, one lane
@@ -82,8 +92,8 @@ int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf,
  * nodes are repeated W = walk_mod times). */
 int ps_walk_paths(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                   const int64_t *starts, int64_t B, int L, int rng_mode, const double *uniforms,
-                  const int64_t *uoff, uint64_t seed, uint32_t call, int walk_mod, int32_t *paths,
-                  ps_stream_t stream);
+                  const int64_t *uoff, uint64_t seed, uint32_t call, int walk_mod,
+                  const uint32_t *nodeinfo, const int32_t *guide, int32_t *paths, ps_stream_t stream);
 
 /* Offsets into the numpy stream: uoff[i] = W*L * #{j < i : outdeg(starts[j]) > 0};
  * total[0] = uniforms consumed by the whole batch. */

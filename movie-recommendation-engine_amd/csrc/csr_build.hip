@@ -149,6 +149,31 @@ __global__ __launch_bounds__(256) void cdf_large_kernel(const int64_t *rowptr, c
     }
 }
 
+// one wave per row: guide[lo + j] = #{k : cdf[lo + k] <= (j - 1) / deg}; nodeinfo[v] = (lo, deg)
+__global__ __launch_bounds__(256) void guide_build_kernel(const int64_t *rowptr, const double *cdf, int64_t V,
+                                                          uint32_t *nodeinfo, int32_t *guide) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t v = wave; v < V; v += nwaves) {
+        const int64_t lo = rowptr[v], hi = rowptr[v + 1], d = hi - lo;
+        if (lane == 0) { nodeinfo[2 * v] = (uint32_t)lo; nodeinfo[2 * v + 1] = (uint32_t)d; }
+        for (int64_t j = lane; j < d; j += 64) {
+            int64_t l = lo, h = hi;
+            if (j == 0) {
+                h = lo;
+            } else {
+                const double t = (double)(j - 1) / (double)d;
+                while (l < h) {
+                    const int64_t mid = l + ((h - l) >> 1);
+                    if (cdf[mid] <= t) l = mid + 1; else h = mid;
+                }
+            }
+            guide[lo + j] = (int32_t)(h - lo);
+        }
+    }
+}
+
 int radix_bits(int64_t V) {
     int bits = 1;
     while (((int64_t)1 << bits) < V && bits < 32) ++bits;
@@ -198,6 +223,18 @@ extern "C" int ps_csr_build(const int64_t *src, const int64_t *dst, const float 
     hipLaunchKernelGGL(rowptr_kernel, dim3((unsigned)grid), dim3(256), 0, st, keys_out, E, V, rowptr);
     PS_CHECK_LAUNCH();
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)grid), dim3(256), 0, st, vals_out, dst, w, E, col, wsorted);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+extern "C" int ps_guide_build(const int64_t *rowptr, const double *cdf, int64_t V, uint32_t *nodeinfo, int32_t *guide,
+                              ps_stream_t stream) {
+    if (!rowptr || V < 0) return PS_EINVAL;
+    if (V == 0) return PS_OK;
+    if (!nodeinfo || !cdf || !guide) return PS_EINVAL;
+    int64_t g = ps_cdiv(V, 4);
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(guide_build_kernel, dim3((unsigned)g), dim3(256), 0, ps_stream(stream), rowptr, cdf, V, nodeinfo, guide);
     PS_CHECK_LAUNCH();
     return PS_OK;
 }

@@ -4,70 +4,135 @@
 // utils/nearest_neighbors.py:47-68): every query is compared with ALL ntotal codes
 // (popcount of XOR) and the k smallest by (distance, id) are returned in ascending order.
 //
-// Mapping: one lane = one query (its code lives in registers), a wave = 64 queries sweeping a
-// contiguous slice of the code table.  The table word is wave-uniform, so it is fetched through
-// the scalar cache and each 32-bit word costs two VALU ops per 64 queries (v_xor + v_bcnt
-// accumulate).  Each lane keeps its k best (distance<<32 | local id) keys sorted in an LDS column;
-// ids ascend during the sweep, so "key < current worst" is exactly faiss' strict-less admission.
-// Slices of the table are swept by different waves and merged by ps_topk_merge's kernel.
+// Slices of the table are swept by different waves (see hamming_scan_kernel) and merged by
+// ps_topk_merge's kernel.
 #include "ps_common.h"
 
 namespace {
 
-constexpr uint64_t EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
 
-template <int WORDS>
+// One wave = up to QT (<= 64) queries x one slice of the code table.  Lanes own db items: a chunk of G
+// 64-item groups is loaded once (coalesced, G * WORDS registers per lane) and compared with every query of
+// the tile; the query code is wave-uniform, so it comes in through scalar loads (the next query's code is
+// requested before the current one is consumed) and costs no vector registers or LDS.  Per 32-bit word
+// and 64 (query, item) pairs: v_xor + v_bcnt accumulate.
+// Top-k: lane qi of `tau` holds query qi's admission bound (its current k-th best key, distance << 32 |
+// local id); a ballot of "key < tau" is almost always empty.  Otherwise the wave-uniform rare path pulls
+// that query's sorted list out of LDS (lane p = p-th best), inserts the candidates in lane (= id) order --
+// position by ballot + popcount, shift by one lane -- and stores it back.  No divergence, no atomics; ids
+// ascend during the sweep, so "key < current worst" is exactly faiss' strict-less admission.
+// lane p receives lane p-1's value (lane 0 keeps its own): DPP wave_shr:1, no LDS crossbar round trip
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+template <int WORDS, int G>
 __global__ __launch_bounds__(256) void hamming_scan_kernel(const uint32_t *__restrict__ q, int64_t nq,
                                                            const uint32_t *__restrict__ codes, int64_t N, int k,
-                                                           int splits, int64_t id_offset, int32_t *__restrict__ odist,
-                                                           int64_t *__restrict__ oids) {
-    extern __shared__ uint64_t skeys[];   // [4 waves][k][64 lanes]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint64_t *col = skeys + (size_t)wv * k * 64 + lane;   // this lane's column: col[p * 64]
-    const int64_t gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
-    const int64_t ngroups = (nq + 63) / 64;
-    if (gw >= ngroups * splits) return;
-    const int64_t qg = gw / splits;
-    const int split = (int)(gw % splits);
+                                                           int kcap, int QT, int splits, int64_t id_offset,
+                                                           int32_t *__restrict__ odist, int64_t *__restrict__ oids) {
+    extern __shared__ uint64_t lists_all[];                           // [4 waves][QT][kcap]
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    uint64_t *L = lists_all + (size_t)wv * QT * kcap;
+    const int64_t gw = (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
+    const int64_t ntiles = (nq + QT - 1) / QT;
+    if (gw >= ntiles * splits) return;
+    const int64_t tile = gw / splits;
+    const int split = (int)(gw - tile * splits);
     const int64_t per = (N + splits - 1) / splits;
     const int64_t j0 = split * per;
     const int64_t j1 = (j0 + per < N) ? (j0 + per) : N;
-    const int64_t qi = qg * 64 + lane;
-    const bool qact = qi < nq;
+    const int64_t q0 = tile * QT;
+    const int nqt = (int)((nq - q0) < QT ? (nq - q0) : QT);
+    const bool vec_ok = (WORDS % 4 == 0) && (reinterpret_cast<size_t>(codes) % 16 == 0);
 
-    uint32_t qc[WORDS];
-#pragma unroll
-    for (int w = 0; w < WORDS; ++w) qc[w] = qact ? q[qi * WORDS + w] : 0u;
-    for (int p = 0; p < k; ++p) col[p * 64] = EMPTY_KEY;
-    uint64_t worst = qact ? EMPTY_KEY : 0ull;
-    int filled = 0;
+    for (int i = lane; i < QT * kcap; i += 64) L[i] = 0xffffffffffffffffull;
+    ps_wave_lds_sync();
+    uint32_t tau_lo = 0xffffffffu, tau_hi = 0xffffffffu;             // lane qi: admission bound of query qi
 
-    for (int64_t j = j0; j < j1; ++j) {
-        const uint32_t *c = codes + j * WORDS;   // wave-uniform address -> scalar loads
-        uint32_t d = 0;
+    for (int64_t g = j0; g < j1; g += 64 * G) {
+        uint32_t it[G][WORDS];
+        uint32_t klo[G];
+        bool valid[G];
 #pragma unroll
-        for (int w = 0; w < WORDS; ++w) d += __builtin_popcount(qc[w] ^ c[w]);
-        const uint64_t key = ((uint64_t)d << 32) | (uint32_t)(j - j0);
-        if (key < worst) {                       // rare once the list is warm
-            int p = filled < k ? filled : k - 1;
-            while (p > 0 && col[(p - 1) * 64] > key) { col[p * 64] = col[(p - 1) * 64]; --p; }
-            col[p * 64] = key;
-            if (filled < k) ++filled;
-            if (filled == k) worst = col[(k - 1) * 64];
-        }
-    }
-    if (qact) {
-        for (int p = 0; p < k; ++p) {
-            const uint64_t key = col[p * 64];
-            const int64_t o = ((int64_t)split * nq + qi) * k + p;
-            if (p < filled) {
-                odist[o] = (int32_t)(key >> 32);
-                oids[o] = (int64_t)(uint32_t)key + j0 + id_offset;
+        for (int gg = 0; gg < G; ++gg) {
+            const int64_t j = g + gg * 64 + lane;
+            valid[gg] = j < j1;
+            klo[gg] = (uint32_t)(j - j0);
+            if (vec_ok) {
+#pragma unroll
+                for (int w = 0; w < WORDS; w += 4) {
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (valid[gg]) v = *reinterpret_cast<const uint4 *>(codes + j * WORDS + w);
+                    it[gg][w] = v.x; it[gg][w + 1 < WORDS ? w + 1 : w] = v.y;
+                    it[gg][w + 2 < WORDS ? w + 2 : w] = v.z; it[gg][w + 3 < WORDS ? w + 3 : w] = v.w;
+                }
             } else {
-                odist[o] = 0x7fffffff;
-                oids[o] = -1;
+#pragma unroll
+                for (int w = 0; w < WORDS; ++w) it[gg][w] = valid[gg] ? codes[j * WORDS + w] : 0u;
             }
         }
+        uint32_t cur[WORDS];
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) cur[w] = q[q0 * WORDS + w];   // wave-uniform -> scalar load
+        for (int qi = 0; qi < nqt; ++qi) {                            // scalar loop
+            const int qn = (qi + 1 < nqt) ? qi + 1 : qi;
+            uint32_t nxt[WORDS];
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) nxt[w] = q[(q0 + qn) * WORDS + w];   // in flight during the compares
+            uint32_t tlo = __builtin_amdgcn_readlane(tau_lo, qi);
+            uint32_t thi = __builtin_amdgcn_readlane(tau_hi, qi);
+            uint32_t d[G];
+            uint64_t m[G];
+            uint64_t many = 0ull;
+#pragma unroll
+            for (int gg = 0; gg < G; ++gg) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int w = 0; w < WORDS; ++w) acc += __builtin_popcount(it[gg][w] ^ cur[w]);
+                d[gg] = acc;
+                m[gg] = __ballot(valid[gg] && (acc < thi || (acc == thi && klo[gg] < tlo)));
+                many |= m[gg];
+            }
+            if (many != 0ull) {                                        // rare, wave-uniform
+                uint64_t lk = (lane < kcap) ? L[qi * kcap + lane] : 0xffffffffffffffffull;
+                uint32_t llo = (uint32_t)lk, lhi = (uint32_t)(lk >> 32);
+#pragma unroll
+                for (int gg = 0; gg < G; ++gg) {
+                    // candidates of this group against the CURRENT bound (it tightens with every insertion,
+                    // so stale candidates drop out of the ballot instead of being visited one by one)
+                    uint64_t mask = __ballot(valid[gg] && (d[gg] < thi || (d[gg] == thi && klo[gg] < tlo)));
+                    while (mask != 0ull) {
+                        const int b = __builtin_ctzll(mask);
+                        const uint32_t clo = __builtin_amdgcn_readlane(klo[gg], b);
+                        const uint32_t chi = __builtin_amdgcn_readlane(d[gg], b);
+                        const uint64_t lt = __ballot(lhi < chi || (lhi == chi && llo < clo));
+                        const int pos = __popcll(lt);                  // the list is sorted: lt is a prefix
+                        const uint32_t slo = wave_shr1(llo), shi = wave_shr1(lhi);
+                        if (lane == pos) { llo = clo; lhi = chi; }
+                        else if (lane > pos) { llo = slo; lhi = shi; }
+                        tlo = __builtin_amdgcn_readlane(llo, k - 1);
+                        thi = __builtin_amdgcn_readlane(lhi, k - 1);
+                        const uint64_t above = (b == 63) ? 0ull : (~0ull << (b + 1));
+                        mask = __ballot(valid[gg] && (d[gg] < thi || (d[gg] == thi && klo[gg] < tlo))) & above;
+                    }
+                }
+                if (lane < kcap) L[qi * kcap + lane] = ((uint64_t)lhi << 32) | llo;
+                if (lane == qi) { tau_lo = tlo; tau_hi = thi; }
+            }
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) cur[w] = nxt[w];
+        }
+    }
+    ps_wave_lds_sync();
+    for (int i = lane; i < nqt * k; i += 64) {
+        const int qi = i / k, p = i - qi * k;
+        const uint64_t key = L[qi * kcap + p];
+        const int64_t o = ((int64_t)split * nq + q0 + qi) * k + p;
+        const bool has = key != 0xffffffffffffffffull;
+        odist[o] = has ? (int32_t)(key >> 32) : 0x7fffffff;
+        oids[o] = has ? (int64_t)(uint32_t)key + j0 + id_offset : -1;
     }
 }
 
@@ -111,12 +176,14 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const int32_t *__restri
     }
 }
 
+constexpr int QUERY_TILE = 32;
+
 int pick_splits(int64_t nq, int64_t N) {
-    const int64_t groups = (nq + 63) / 64;
-    int64_t s = (256 * 8 + groups - 1) / groups;   // aim at >= 2048 waves
+    const int64_t tiles = (nq + QUERY_TILE - 1) / QUERY_TILE;
+    int64_t s = (256 * 10 + tiles - 1) / tiles;      // aim at >= 2560 waves
     if (s < 1) s = 1;
     if (s > 1024) s = 1024;
-    while (s > 1 && N / s < 64) s >>= 1;           // keep slices worth sweeping
+    while (s > 1 && N / s < 1024) s >>= 1;           // keep slices worth sweeping
     return (int)s;
 }
 
@@ -146,7 +213,7 @@ extern "C" int ps_hamming_topk(const uint8_t *qcodes, int64_t nq, const uint8_t 
                                ps_stream_t stream) {
     if (nq < 0 || N < 0 || cs <= 0 || k <= 0) return PS_EINVAL;
     if (cs % 4 != 0) return PS_EUNSUPPORTED;
-    if (k > 160) return PS_EUNSUPPORTED;            // 4 waves * k * 64 lanes * 8 B of LDS
+    if (k > 64) return PS_EUNSUPPORTED;             // the k best keys of a query live across the 64 lanes
     if (nq == 0) return PS_OK;
     if (!qcodes || !dist || !ids || (N > 0 && !codes)) return PS_EINVAL;
     if ((reinterpret_cast<size_t>(qcodes) | reinterpret_cast<size_t>(codes)) % 4 != 0) return PS_EINVAL;
@@ -163,14 +230,16 @@ extern "C" int ps_hamming_topk(const uint8_t *qcodes, int64_t nq, const uint8_t 
         ci = reinterpret_cast<int64_t *>(base);
         cd = reinterpret_cast<int32_t *>(base + (size_t)s * nq * k * sizeof(int64_t));
     }
-    const int64_t waves = ((nq + 63) / 64) * s;
+    const int64_t waves = ((nq + QUERY_TILE - 1) / QUERY_TILE) * s;
     const unsigned grid = (unsigned)ps_cdiv(waves, 4);
-    const size_t lds = (size_t)4 * k * 64 * sizeof(uint64_t);
+    int kcap = 16;
+    while (kcap < k) kcap <<= 1;
+    const size_t lds = (size_t)4 * QUERY_TILE * kcap * sizeof(uint64_t);
     const uint32_t *q32 = reinterpret_cast<const uint32_t *>(qcodes);
     const uint32_t *c32 = reinterpret_cast<const uint32_t *>(codes);
-#define PS_LAUNCH_SCAN(WORDS_)                                                                                     \
-    hipLaunchKernelGGL(hamming_scan_kernel<WORDS_>, dim3(grid), dim3(256), lds, st, q32, nq, c32, N, k, s, id_offset, \
-                       cd, ci)
+#define PS_LAUNCH_SCAN(WORDS_)                                                                                  \
+    hipLaunchKernelGGL((hamming_scan_kernel<WORDS_, (WORDS_ >= 32 ? 2 : 4)>), dim3(grid), dim3(256), lds, st, q32, nq, \
+                       c32, N, k, kcap, QUERY_TILE, s, id_offset, cd, ci)
     switch (words) {
         case 1: PS_LAUNCH_SCAN(1); break;
         case 2: PS_LAUNCH_SCAN(2); break;

@@ -27,6 +27,8 @@ struct WalkArgs {
     const double *uniforms;
     const int64_t *uoff;
     uint32_t seed_lo, seed_hi, call;
+    const uint32_t *nodeinfo;
+    const int32_t *guide;
     int32_t *ids;
     int32_t *counts;
     int32_t *nvalid;
@@ -54,6 +56,36 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
     uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
     return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+constexpr int LIN_PROBES = 12;   // forward-scan probes after the guide lookup before falling back to bisection
+
+// (row start, out-degree) of node v: one 8-byte record when nodeinfo is present
+__device__ __forceinline__ void load_row(const int64_t *rowptr, const uint32_t *nodeinfo, int64_t v, int64_t &lo,
+                                         int64_t &hi) {
+    if (nodeinfo) {
+        const uint2 ni = reinterpret_cast<const uint2 *>(nodeinfo)[v];
+        lo = ni.x;
+        hi = lo + ni.y;
+    } else {
+        lo = rowptr[v];
+        hi = rowptr[v + 1];
+    }
+}
+
+// Start state of searchsorted(cdf[lo:hi], u, 'right'): with a guide table the search starts at the bucket
+// floor(u * deg) (guide = #{cdf <= (j-1)/deg} <= answer) and first scans forward; `n` counts probes.
+__device__ __forceinline__ void search_init(const int32_t *guide, int64_t lo, int64_t hi, double u, int64_t &l,
+                                            int &n) {
+    l = lo;
+    n = LIN_PROBES;
+    if (guide) {
+        const uint32_t deg = (uint32_t)(hi - lo);
+        uint32_t j = (uint32_t)(u * (double)deg);
+        if (j >= deg) j = deg - 1;
+        l = lo + guide[lo + j];
+        n = 0;
+    }
 }
 
 constexpr int WAVES_PER_BLOCK = 4;
@@ -95,33 +127,48 @@ __global__ __launch_bounds__(256) void walk_sample_kernel(WalkArgs a) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) posb[j * 64 + lane] = -1;
         ps_wave_lds_sync();
-        for (int w0 = 0; w0 < a.W; w0 += 64) {
-            const int w = w0 + lane;
-            const bool act = w < a.W;
-            bool alive = act;
-            int64_t cur = s;
+        // two walks per lane (w and w + 64) advance in lockstep: their CDF probes are independent, so
+        // every iteration of the search loop keeps two loads in flight per lane.
+        for (int w0 = 0; w0 < a.W; w0 += 128) {
+            const int wA = w0 + lane, wB = w0 + 64 + lane;
+            const bool actA = wA < a.W, actB = wB < a.W;
+            bool aliveA = actA, aliveB = actB;
+            int64_t curA = s, curB = s;
             for (int st = 0; st < a.L; ++st) {
-                int64_t lo = lo0, hi = hi0;
-                if (st > 0 && alive) {
-                    lo = a.rowptr[cur];
-                    hi = a.rowptr[cur + 1];
+                int64_t loA = lo0, hiA = hi0, loB = lo0, hiB = hi0;
+                if (st > 0) {
+                    if (aliveA) load_row(a.rowptr, a.nodeinfo, curA, loA, hiA);
+                    if (aliveB) load_row(a.rowptr, a.nodeinfo, curB, loB, hiB);
                 }
-                if (hi == lo) alive = false;          // sink: the walk stops (random_walk.py:68-69)
-                int32_t nxt = -1;
-                if (alive) {
-                    double u;
-                    if (a.rng_mode == PS_RNG_STREAM) u = a.uniforms[ubase + (int64_t)w * a.L + st];
-                    else u = philox_uniform(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)w, (uint32_t)st, a.call);
-                    int64_t l = lo, h = hi;
-                    while (l < h) {                   // searchsorted(cdf, u, side='right')
-                        const int64_t mid = l + ((h - l) >> 1);
-                        if (a.cdf[mid] <= u) l = mid + 1; else h = mid;
-                    }
-                    if (l >= hi) l = hi - 1;          // cdf[-1] == 1.0 > u; defensive only
-                    nxt = a.col[l];
-                    cur = nxt;
+                if (hiA == loA) aliveA = false;       // sink: the walk stops (random_walk.py:68-69)
+                if (hiB == loB) aliveB = false;
+                double uA = 2.0, uB = 2.0;
+                if (a.rng_mode == PS_RNG_STREAM) {
+                    if (aliveA) uA = a.uniforms[ubase + (int64_t)wA * a.L + st];
+                    if (aliveB) uB = a.uniforms[ubase + (int64_t)wB * a.L + st];
+                } else {
+                    if (aliveA) uA = philox_uniform(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wA, (uint32_t)st, a.call);
+                    if (aliveB) uB = philox_uniform(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wB, (uint32_t)st, a.call);
                 }
-                if (act) posb[w * a.L + st] = nxt;
+                int64_t lA = loA, hA = loA, lB = loB, hB = loB;
+                int nA_ = 0, nB_ = 0;
+                if (aliveA) { search_init(a.guide, loA, hiA, uA, lA, nA_); hA = hiA; }
+                if (aliveB) { search_init(a.guide, loB, hiB, uB, lB, nB_); hB = hiB; }
+                while (true) {                        // searchsorted(cdf, u, side='right'), two at a time
+                    const bool a_ = lA < hA, b_ = lB < hB;
+                    if (!a_ && !b_) break;
+                    const int64_t mA = (nA_ < LIN_PROBES) ? lA : lA + ((hA - lA) >> 1);
+                    const int64_t mB = (nB_ < LIN_PROBES) ? lB : lB + ((hB - lB) >> 1);
+                    const double cA = a_ ? a.cdf[mA] : 0.0;
+                    const double cB = b_ ? a.cdf[mB] : 0.0;
+                    if (a_) { if (cA <= uA) lA = mA + 1; else hA = mA; ++nA_; }
+                    if (b_) { if (cB <= uB) lB = mB + 1; else hB = mB; ++nB_; }
+                }
+                int32_t nA = -1, nB = -1;
+                if (aliveA) { if (lA >= hiA) lA = hiA - 1; nA = a.col[lA]; curA = nA; }   // cdf[-1] == 1.0 > u
+                if (aliveB) { if (lB >= hiB) lB = hiB - 1; nB = a.col[lB]; curB = nB; }
+                if (actA) posb[wA * a.L + st] = nA;
+                if (actB) posb[wB * a.L + st] = nB;
             }
         }
         // ---------------- count phase -------------------------------------------------
@@ -187,7 +234,7 @@ __global__ __launch_bounds__(256) void walk_sample_kernel(WalkArgs a) {
 __global__ void walk_paths_kernel(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                                   const int64_t *starts, int64_t B, int L, int rng_mode, const double *uniforms,
                                   const int64_t *uoff, uint32_t k0, uint32_t k1, uint32_t call, int walk_mod,
-                                  int32_t *paths) {
+                                  const uint32_t *nodeinfo, const int32_t *guide, int32_t *paths) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = starts[i];
         int64_t cur = s;
@@ -196,17 +243,21 @@ __global__ void walk_paths_kernel(const int64_t *rowptr, const int32_t *col, con
         for (int st = 0; st < L; ++st) {
             int32_t nxt = -1;
             if (alive) {
-                const int64_t lo = rowptr[cur], hi = rowptr[cur + 1];
+                int64_t lo, hi;
+                load_row(rowptr, nodeinfo, cur, lo, hi);
                 if (hi == lo) {
                     alive = false;
                 } else {
                     double u;
                     if (rng_mode == PS_RNG_STREAM) u = uniforms[ubase + st];
                     else u = philox_uniform(k0, k1, (uint32_t)s, (uint32_t)(walk_mod > 0 ? i % walk_mod : i), (uint32_t)st, call);
-                    int64_t l = lo, h = hi;
+                    int64_t l, h = hi;
+                    int n;
+                    search_init(guide, lo, hi, u, l, n);
                     while (l < h) {
-                        const int64_t mid = l + ((h - l) >> 1);
+                        const int64_t mid = (n < LIN_PROBES) ? l : l + ((h - l) >> 1);
                         if (cdf[mid] <= u) l = mid + 1; else h = mid;
+                        ++n;
                     }
                     if (l >= hi) l = hi - 1;
                     nxt = col[l];
@@ -274,21 +325,23 @@ __global__ void graph_stats_kernel(const int64_t *rowptr, const int32_t *col, in
 extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                               const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
                               const double *uniforms, const int64_t *uoff, uint64_t seed, uint32_t call,
+                              const uint32_t *nodeinfo, const int32_t *guide,
                               int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream) {
     if (B < 0 || W <= 0 || L <= 0 || T <= 0 || V < 0) return PS_EINVAL;
     if (B == 0) return PS_OK;
     if (!rowptr || !col || !cdf || !starts || !ids || !counts || !nvalid) return PS_EINVAL;
     if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX) return PS_EINVAL;
     if (rng_mode == PS_RNG_STREAM && (!uniforms || !uoff)) return PS_EINVAL;
+    if ((nodeinfo == nullptr) != (guide == nullptr)) return PS_EINVAL;
     const int64_t P = (int64_t)W * L;
     if (P > 1024) return PS_EUNSUPPORTED;
     if (B == 0) return PS_OK;
     int np = 1;
     while (np * 64 < P) np <<= 1;
     int hs_log2 = 6;
-    while ((1 << hs_log2) < 2 * P) ++hs_log2;
+    while ((1 << hs_log2) * 4 < 5 * P) ++hs_log2;      // table >= 1.25 P slots (load factor <= 0.8)
     WalkArgs a{rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff,
-               (uint32_t)seed, (uint32_t)(seed >> 32), call, ids, counts, nvalid, hs_log2};
+               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, ids, counts, nvalid, hs_log2};
     const size_t lds = (size_t)WAVES_PER_BLOCK * (np * 64 + 3 * (1 << hs_log2) + BITMAP_WORDS) * sizeof(int32_t);
     int64_t grid = ps_cdiv(B, WAVES_PER_BLOCK);
     if (grid > 256 * 32) grid = 256 * 32;
@@ -307,17 +360,18 @@ extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const d
 
 extern "C" int ps_walk_paths(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                              const int64_t *starts, int64_t B, int L, int rng_mode, const double *uniforms,
-                             const int64_t *uoff, uint64_t seed, uint32_t call, int walk_mod, int32_t *paths,
-                             ps_stream_t stream) {
+                             const int64_t *uoff, uint64_t seed, uint32_t call, int walk_mod,
+                             const uint32_t *nodeinfo, const int32_t *guide, int32_t *paths, ps_stream_t stream) {
     if (B < 0 || L <= 0) return PS_EINVAL;
     if (B == 0) return PS_OK;
     if (!rowptr || !col || !cdf || !starts || !paths) return PS_EINVAL;
     if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX) return PS_EINVAL;
     if (rng_mode == PS_RNG_STREAM && (!uniforms || !uoff)) return PS_EINVAL;
+    if ((nodeinfo == nullptr) != (guide == nullptr)) return PS_EINVAL;
     int64_t grid = ps_cdiv(B, 256);
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(walk_paths_kernel, dim3((unsigned)grid), dim3(256), 0, ps_stream(stream), rowptr, col, cdf, V,
-                       starts, B, L, rng_mode, uniforms, uoff, (uint32_t)seed, (uint32_t)(seed >> 32), call, walk_mod, paths);
+                       starts, B, L, rng_mode, uniforms, uoff, (uint32_t)seed, (uint32_t)(seed >> 32), call, walk_mod, nodeinfo, guide, paths);
     PS_CHECK_LAUNCH();
     return PS_OK;
 }

@@ -46,6 +46,12 @@ class DeviceGraph:
             nv.call("ps_csr_build", nv.ptr(src), nv.ptr(dst), nv.ptr(w), nv.i64(E), nv.i64(V), nv.ptr(self.rowptr),
                                     nv.ptr(self.col), nv.ptr(wsorted), nv.ptr(ws), nv.C.c_size_t(ws_bytes), nv.stream())
             nv.call("ps_cdf_build", nv.ptr(self.rowptr), nv.ptr(wsorted), nv.i64(V), nv.ptr(self.cdf), nv.stream())
+            # exact lookup accelerators for the walk kernels: packed (row start, degree) + bucket table
+            self.nodeinfo = torch.empty(2 * V, dtype=torch.int32, device=dev)
+            self.guide = torch.empty(E, dtype=torch.int32, device=dev)
+            if E:
+                nv.call("ps_guide_build", nv.ptr(self.rowptr), nv.ptr(self.cdf), nv.i64(V), nv.ptr(self.nodeinfo),
+                        nv.ptr(self.guide), nv.stream())
             flags = torch.zeros(2, dtype=torch.int64, device=dev)
             nv.call("ps_graph_stats", nv.ptr(self.rowptr), nv.ptr(self.col), nv.i64(E), nv.i64(V), nv.ptr(flags),
                                       nv.stream())
@@ -56,4 +62,4 @@ class DeviceGraph:
         del ws
 
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.cdf))
+        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.cdf, self.nodeinfo, self.guide))

@@ -88,12 +88,19 @@ class LazyNeighborList(list):
         return (list, (list(super().__iter__()),))
 
 
-def _nodes_tensor(nodes, device):
-    if isinstance(nodes, torch.Tensor):
-        t = nodes.to(device=device, dtype=torch.int64)
-    else:
-        t = torch.as_tensor(np.asarray(nodes, dtype=np.int64), device=device)
-    return t.reshape(-1).contiguous()
+def _nodes_tensor(nodes, device, num_nodes):
+    """int64 device tensor of start nodes.  Host inputs (lists / numpy / CPU tensors) are range-checked
+    here like the reference's `adj_list[node]` (utils/random_walk.py:66 -> IndexError); tensors already
+    on the device are not synchronised on: the kernels treat out-of-range ids as isolated nodes."""
+    if isinstance(nodes, torch.Tensor) and nodes.is_cuda:
+        return nodes.to(device=device, dtype=torch.int64).reshape(-1).contiguous()
+    a = nodes.numpy() if isinstance(nodes, torch.Tensor) else np.asarray(nodes)
+    a = a.astype(np.int64, copy=False).reshape(-1)
+    if a.size and (a.min() < -num_nodes or a.max() >= num_nodes):
+        raise IndexError("list index out of range")
+    if a.size and a.min() < 0:
+        a = np.where(a < 0, a + num_nodes, a)            # python negative indexing into adj_list
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
 def draw_numpy_uniforms(n, device):
@@ -106,15 +113,13 @@ def draw_numpy_uniforms(n, device):
     return t.to(device, non_blocking=True)
 
 
-def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None):
+def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None, use_guide=True):
     """batch_sample_neighbors on the device.  rng='numpy': the global numpy stream (bit-exact with
     the reference; needs a graph without reachable sinks); rng='philox': counter-based.
     `uniforms` (device fp64) overrides the numpy draw (tests / multi-GPU shards)."""
     dev = graph.device
-    starts = _nodes_tensor(nodes, dev)
+    starts = _nodes_tensor(nodes, dev, graph.V)
     B = int(starts.numel())
-    if B and (int(starts.min()) < 0 or int(starts.max()) >= graph.V):
-        raise IndexError("list index out of range")      # reference: adj_list[node] (utils/random_walk.py:66)
     ids = torch.empty((B, T), dtype=torch.int32, device=dev)
     counts = torch.empty((B, T), dtype=torch.int32, device=dev)
     nvalid = torch.empty(B, dtype=torch.int32, device=dev)
@@ -141,6 +146,8 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
         nv.call("ps_walk_sample", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
                                    nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T), nv.i32(mode),
                                    nv.ptr(uniforms), nv.ptr(uoff), nv.u64(seed & (2 ** 64 - 1)), nv.u32(call),
+                                   nv.ptr(graph.nodeinfo) if use_guide else nv.ptr(None),
+                                   nv.ptr(graph.guide) if use_guide else nv.ptr(None),
                                    nv.ptr(ids), nv.ptr(counts), nv.ptr(nvalid), nv.stream())
     return NeighborBatch(ids, counts, nvalid)
 
@@ -148,10 +155,8 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
 def walk_paths(graph, starts, L, rng="numpy", seed=0, call=0, walk_mod=0):
     """One walk per start node: int32[B,L] visited nodes (-1 after a sink)."""
     dev = graph.device
-    st = _nodes_tensor(starts, dev)
+    st = _nodes_tensor(starts, dev, graph.V)
     B = int(st.numel())
-    if B and (int(st.min()) < 0 or int(st.max()) >= graph.V):
-        raise IndexError("list index out of range")
     paths = torch.empty((B, L), dtype=torch.int32, device=dev)
     L_ = nv.lib()
     with torch.cuda.device(dev):
@@ -168,7 +173,8 @@ def walk_paths(graph, starts, L, rng="numpy", seed=0, call=0, walk_mod=0):
             uoff, uniforms, mode = None, None, nv.PS_RNG_PHILOX
         nv.call("ps_walk_paths", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
                                   nv.ptr(st), nv.i64(B), nv.i32(L), nv.i32(mode), nv.ptr(uniforms), nv.ptr(uoff),
-                                  nv.u64(seed & (2 ** 64 - 1)), nv.u32(call), nv.i32(walk_mod), nv.ptr(paths), nv.stream())
+                                  nv.u64(seed & (2 ** 64 - 1)), nv.u32(call), nv.i32(walk_mod), nv.ptr(graph.nodeinfo),
+                                  nv.ptr(graph.guide), nv.ptr(paths), nv.stream())
     return paths
 
 

@@ -153,3 +153,27 @@ def test_importance_pool_golden_and_oracle(golden):
         out = sampling.importance_pool(torch.from_numpy(x).to(dev), ids=torch.from_numpy(idn.astype(np.int32)).to(dev),
                                        counts=torch.from_numpy(cnt).to(dev), nvalid=torch.from_numpy(nvv).to(dev))
         np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_guide_table_is_exact_on_skewed_weights():
+    """The bucket-table lookup must return searchsorted's answer for any weights: rows whose weights span
+    9 orders of magnitude force long forward scans and the bisection fallback."""
+    from oracle import c_oracle as co
+    from pinsage_hip import sampling
+    from pinsage_hip.graph import DeviceGraph
+    rs = np.random.RandomState(4)
+    ei, _ = bipartite_graph(400, 300, 60000, 13, None)
+    n = ei.shape[1] // 2
+    w = np.exp(rs.uniform(np.log(1e-4), np.log(1e5), size=n)).astype(np.float32)
+    w[rs.randint(0, n, size=50)] = 1e7                       # a few dominant edges
+    ew = np.concatenate([w, w])
+    g = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew))
+    cg = co.Graph(ei, ew, threads=4)
+    assert np.array_equal(g.cdf.cpu().numpy(), cg.cdf)
+    nodes = np.arange(700)
+    a = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=True)
+    b = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=False)
+    ids, counts, nv, _, _, _ = co.walk_sample(cg, nodes, 20, 3, 100, philox=(5, 0), threads=8)
+    for x in (a, b):
+        assert np.array_equal(x.ids.cpu().numpy(), ids) and np.array_equal(x.counts.cpu().numpy(), counts)
+        assert np.array_equal(x.nvalid.cpu().numpy(), nv)
