@@ -57,11 +57,18 @@ int ps_cdf_build(const int64_t *rowptr, const double *wsorted, int64_t V, double
 
 /* Acceleration records for the walk kernels (exact, results unchanged):
  *  nodeinfo uint32[2V] : (row start, out-degree) of every node in one 8-byte record;
- *  guide    int32[E]   : guide[lo_v + j] = #{k : cdf_v[k] <= (j-1)/deg_v}, j = 0..deg_v-1 -- a bucket table
+ *  guide    int32[E]   : guide[lo_v + j] = #{k : cdf_v[k] <= (j/deg_v)(1 - 2^-50)}, j = 0..deg_v-1 -- a bucket table
  *  for the inverse-CDF lookup: searchsorted(cdf_v, u, 'right') starts at guide[lo_v + floor(u*deg_v)] and
- *  scans forward (usually 1-2 entries) instead of probing log2(deg) cache lines. */
+ *  scans forward (usually 1-2 entries) instead of probing log2(deg) cache lines; the threshold sits a hair
+ *  below j/deg so that fp64 rounding of u*deg can never put the start past the answer. */
 int ps_guide_build(const int64_t *rowptr, const double *cdf, int64_t V, uint32_t *nodeinfo, int32_t *guide,
                    ps_stream_t stream);
+
+/* Packed edge blocks: every 8 consecutive edges e = 8b..8b+7 become one 128-byte line
+ *   [ 8 x fp64 cdf | 8 x int32 col | 8 x int32 guide ]   (packed: 128 * ceil(E/8) bytes, 128-B aligned)
+ * so the bucket lookup, the CDF scan and the destination read of one walk step usually hit the same line. */
+int ps_pack_edges(const int32_t *col, const double *cdf, const int32_t *guide, int64_t E, void *packed,
+                  ps_stream_t stream);
 
 /* flags[0] = 1 iff some edge points at a node with out-degree 0 (a reachable sink: the
  * reference's walk then breaks early, utils/random_walk.py:68-69, and its RNG consumption
@@ -78,12 +85,13 @@ int ps_graph_stats(const int64_t *rowptr, const int32_t *col, int64_t E, int64_t
  * Out: ids int32[B,T] (-1 pad), counts int32[B,T] (0 pad), nvalid int32[B].
  * The reference's weights are counts[i,j] / sum_j counts[i,:nvalid[i]] (:113-115).
  * nodeinfo/guide (both or neither; from ps_guide_build) select the bucket-table lookup; NULL = plain
- * binary search over the CDF row. */
+ * binary search over the CDF row.  packed (from ps_pack_edges; needs nodeinfo) reads cdf/col/guide from
+ * the interleaved 128-byte blocks instead of the three arrays. */
 int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                    const int64_t *starts, int64_t B, int W, int L, int T,
                    int rng_mode, const double *uniforms, const int64_t *uoff,
                    uint64_t seed, uint32_t call, const uint32_t *nodeinfo, const int32_t *guide,
-                   int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream);
+                   const void *packed, int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream);
 
 /* _single_walk (utils/random_walk.py:52-83), batched: one walk of L steps per start node, one lane
  * per walk.  paths int32[B,L]: the visited nodes after the start (-1 once the walk hit a sink).

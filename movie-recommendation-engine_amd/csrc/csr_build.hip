@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256) void cdf_large_kernel(const int64_t *rowptr, c
     }
 }
 
-// one wave per row: guide[lo + j] = #{k : cdf[lo + k] <= (j - 1) / deg}; nodeinfo[v] = (lo, deg)
+// one wave per row: guide[lo + j] = #{k : cdf[lo + k] <= (j / deg) * (1 - 2^-50)}; nodeinfo[v] = (lo, deg).
+// Every u with (uint32)(u * deg) == j satisfies u >= (j / deg) * (1 - 2^-53) > that threshold (even with a
+// couple of ulps of error in the division), so guide[lo + j] <= searchsorted(cdf, u, 'right'): a safe start.
 __global__ __launch_bounds__(256) void guide_build_kernel(const int64_t *rowptr, const double *cdf, int64_t V,
                                                           uint32_t *nodeinfo, int32_t *guide) {
     const int lane = threadIdx.x & 63;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void guide_build_kernel(const int64_t *rowptr,
             if (j == 0) {
                 h = lo;
             } else {
-                const double t = (double)(j - 1) / (double)d;
+                const double t = ((double)j / (double)d) * (1.0 - 0x1p-50);
                 while (l < h) {
                     const int64_t mid = l + ((h - l) >> 1);
                     if (cdf[mid] <= t) l = mid + 1; else h = mid;
@@ -171,6 +173,19 @@ __global__ __launch_bounds__(256) void guide_build_kernel(const int64_t *rowptr,
             }
             guide[lo + j] = (int32_t)(h - lo);
         }
+    }
+}
+
+__global__ void pack_edges_kernel(const int32_t *col, const double *cdf, const int32_t *guide, int64_t E,
+                                  unsigned char *packed) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ((E + 7) / 8) * 8;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        unsigned char *blk = packed + (e >> 3) * 128;
+        const int sl = (int)(e & 7);
+        const bool ok = e < E;
+        reinterpret_cast<double *>(blk)[sl] = ok ? cdf[e] : 2.0;
+        reinterpret_cast<int32_t *>(blk + 64)[sl] = ok ? col[e] : -1;
+        reinterpret_cast<int32_t *>(blk + 96)[sl] = ok ? guide[e] : 0;
     }
 }
 
@@ -235,6 +250,19 @@ extern "C" int ps_guide_build(const int64_t *rowptr, const double *cdf, int64_t 
     int64_t g = ps_cdiv(V, 4);
     if (g > 256 * 16) g = 256 * 16;
     hipLaunchKernelGGL(guide_build_kernel, dim3((unsigned)g), dim3(256), 0, ps_stream(stream), rowptr, cdf, V, nodeinfo, guide);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+extern "C" int ps_pack_edges(const int32_t *col, const double *cdf, const int32_t *guide, int64_t E, void *packed,
+                             ps_stream_t stream) {
+    if (E < 0) return PS_EINVAL;
+    if (E == 0) return PS_OK;
+    if (!col || !cdf || !guide || !packed || reinterpret_cast<size_t>(packed) % 128 != 0) return PS_EINVAL;
+    int64_t g = ps_cdiv(E, 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(pack_edges_kernel, dim3((unsigned)g), dim3(256), 0, ps_stream(stream), col, cdf, guide, E,
+                       reinterpret_cast<unsigned char *>(packed));
     PS_CHECK_LAUNCH();
     return PS_OK;
 }

@@ -29,6 +29,7 @@ struct WalkArgs {
     uint32_t seed_lo, seed_hi, call;
     const uint32_t *nodeinfo;
     const int32_t *guide;
+    const unsigned char *packed;
     int32_t *ids;
     int32_t *counts;
     int32_t *nvalid;
@@ -73,26 +74,35 @@ __device__ __forceinline__ void load_row(const int64_t *rowptr, const uint32_t *
     }
 }
 
+// Edge-record accessors: three arrays, or the interleaved 128-byte blocks [8 cdf | 8 col | 8 guide]
+__device__ __forceinline__ double edge_cdf(const double *cdf, const unsigned char *packed, int64_t e) {
+    return packed ? reinterpret_cast<const double *>(packed + (e >> 3) * 128)[e & 7] : cdf[e];
+}
+__device__ __forceinline__ int32_t edge_col(const int32_t *col, const unsigned char *packed, int64_t e) {
+    return packed ? reinterpret_cast<const int32_t *>(packed + (e >> 3) * 128 + 64)[e & 7] : col[e];
+}
+
 // Start state of searchsorted(cdf[lo:hi], u, 'right'): with a guide table the search starts at the bucket
 // floor(u * deg) (guide = #{cdf <= (j-1)/deg} <= answer) and first scans forward; `n` counts probes.
-__device__ __forceinline__ void search_init(const int32_t *guide, int64_t lo, int64_t hi, double u, int64_t &l,
-                                            int &n) {
+__device__ __forceinline__ void search_init(const int32_t *guide, const unsigned char *packed, int64_t lo, int64_t hi,
+                                            double u, int64_t &l, int &n) {
     l = lo;
     n = LIN_PROBES;
-    if (guide) {
+    if (guide || packed) {
         const uint32_t deg = (uint32_t)(hi - lo);
         uint32_t j = (uint32_t)(u * (double)deg);
         if (j >= deg) j = deg - 1;
-        l = lo + guide[lo + j];
+        const int64_t e = lo + j;
+        l = lo + (packed ? reinterpret_cast<const int32_t *>(packed + (e >> 3) * 128 + 96)[e & 7] : guide[e]);
         n = 0;
     }
 }
 
-constexpr int WAVES_PER_BLOCK = 4;
+constexpr int WAVES_PER_BLOCK = 1;   // one start node per workgroup: the dispatcher load-balances uneven nodes
 constexpr int BITMAP_WORDS = 40;   // counts <= 1024 -> 33 words, padded
 
 template <int NP>
-__global__ __launch_bounds__(256) void walk_sample_kernel(WalkArgs a) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkArgs a) {
     extern __shared__ int32_t smem[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -152,21 +162,48 @@ __global__ __launch_bounds__(256) void walk_sample_kernel(WalkArgs a) {
                 }
                 int64_t lA = loA, hA = loA, lB = loB, hB = loB;
                 int nA_ = 0, nB_ = 0;
-                if (aliveA) { search_init(a.guide, loA, hiA, uA, lA, nA_); hA = hiA; }
-                if (aliveB) { search_init(a.guide, loB, hiB, uB, lB, nB_); hB = hiB; }
-                while (true) {                        // searchsorted(cdf, u, side='right'), two at a time
+                if (aliveA) { search_init(a.guide, a.packed, loA, hiA, uA, lA, nA_); hA = hiA; }
+                if (aliveB) { search_init(a.guide, a.packed, loB, hiB, uB, lB, nB_); hB = hiB; }
+                // searchsorted(cdf, u, side='right') for both walks.  While scanning forward from the guide
+                // start, each iteration looks at two consecutive entries (and their destinations): the loads
+                // are independent, so the dependent chain is half as long; after LIN_PROBES it bisects.
+                int32_t nA = -1, nB = -1;
+                while (true) {
                     const bool a_ = lA < hA, b_ = lB < hB;
                     if (!a_ && !b_) break;
-                    const int64_t mA = (nA_ < LIN_PROBES) ? lA : lA + ((hA - lA) >> 1);
-                    const int64_t mB = (nB_ < LIN_PROBES) ? lB : lB + ((hB - lB) >> 1);
-                    const double cA = a_ ? a.cdf[mA] : 0.0;
-                    const double cB = b_ ? a.cdf[mB] : 0.0;
-                    if (a_) { if (cA <= uA) lA = mA + 1; else hA = mA; ++nA_; }
-                    if (b_) { if (cB <= uB) lB = mB + 1; else hB = mB; ++nB_; }
+                    const bool linA = nA_ < LIN_PROBES, linB = nB_ < LIN_PROBES;
+                    const int64_t mA = linA ? lA : lA + ((hA - lA) >> 1);
+                    const int64_t mB = linB ? lB : lB + ((hB - lB) >> 1);
+                    const bool a2 = a_ && linA && (mA + 1 < hA), b2 = b_ && linB && (mB + 1 < hB);
+                    const double cA0 = a_ ? edge_cdf(a.cdf, a.packed, mA) : 0.0;
+                    const double cB0 = b_ ? edge_cdf(a.cdf, a.packed, mB) : 0.0;
+                    const double cA1 = a2 ? edge_cdf(a.cdf, a.packed, mA + 1) : 2.0;
+                    const double cB1 = b2 ? edge_cdf(a.cdf, a.packed, mB + 1) : 2.0;
+                    const int32_t kA0 = (a_ && linA) ? edge_col(a.col, a.packed, mA) : -1;
+                    const int32_t kB0 = (b_ && linB) ? edge_col(a.col, a.packed, mB) : -1;
+                    const int32_t kA1 = a2 ? edge_col(a.col, a.packed, mA + 1) : -1;
+                    const int32_t kB1 = b2 ? edge_col(a.col, a.packed, mB + 1) : -1;
+                    if (a_) {
+                        if (linA) {
+                            if (cA0 > uA) { hA = mA; lA = mA; nA = kA0; }
+                            else if (cA1 > uA) { lA = mA + 1; hA = lA; nA = kA1; }   // only reachable when a2
+                            else { lA = mA + 2; nA_ += 2; }
+                        } else {
+                            if (cA0 <= uA) lA = mA + 1; else hA = mA;
+                        }
+                    }
+                    if (b_) {
+                        if (linB) {
+                            if (cB0 > uB) { hB = mB; lB = mB; nB = kB0; }
+                            else if (cB1 > uB) { lB = mB + 1; hB = lB; nB = kB1; }
+                            else { lB = mB + 2; nB_ += 2; }
+                        } else {
+                            if (cB0 <= uB) lB = mB + 1; else hB = mB;
+                        }
+                    }
                 }
-                int32_t nA = -1, nB = -1;
-                if (aliveA) { if (lA >= hiA) lA = hiA - 1; nA = a.col[lA]; curA = nA; }   // cdf[-1] == 1.0 > u
-                if (aliveB) { if (lB >= hiB) lB = hiB - 1; nB = a.col[lB]; curB = nB; }
+                if (aliveA) { if (lA >= hiA) lA = hiA - 1; if (nA < 0) nA = edge_col(a.col, a.packed, lA); curA = nA; }
+                if (aliveB) { if (lB >= hiB) lB = hiB - 1; if (nB < 0) nB = edge_col(a.col, a.packed, lB); curB = nB; }
                 if (actA) posb[wA * a.L + st] = nA;
                 if (actB) posb[wB * a.L + st] = nB;
             }
@@ -253,7 +290,7 @@ __global__ void walk_paths_kernel(const int64_t *rowptr, const int32_t *col, con
                     else u = philox_uniform(k0, k1, (uint32_t)s, (uint32_t)(walk_mod > 0 ? i % walk_mod : i), (uint32_t)st, call);
                     int64_t l, h = hi;
                     int n;
-                    search_init(guide, lo, hi, u, l, n);
+                    search_init(guide, nullptr, lo, hi, u, l, n);
                     while (l < h) {
                         const int64_t mid = (n < LIN_PROBES) ? l : l + ((h - l) >> 1);
                         if (cdf[mid] <= u) l = mid + 1; else h = mid;
@@ -325,7 +362,7 @@ __global__ void graph_stats_kernel(const int64_t *rowptr, const int32_t *col, in
 extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                               const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
                               const double *uniforms, const int64_t *uoff, uint64_t seed, uint32_t call,
-                              const uint32_t *nodeinfo, const int32_t *guide,
+                              const uint32_t *nodeinfo, const int32_t *guide, const void *packed,
                               int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream) {
     if (B < 0 || W <= 0 || L <= 0 || T <= 0 || V < 0) return PS_EINVAL;
     if (B == 0) return PS_OK;
@@ -333,6 +370,7 @@ extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const d
     if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX) return PS_EINVAL;
     if (rng_mode == PS_RNG_STREAM && (!uniforms || !uoff)) return PS_EINVAL;
     if ((nodeinfo == nullptr) != (guide == nullptr)) return PS_EINVAL;
+    if (packed && !nodeinfo) return PS_EINVAL;
     const int64_t P = (int64_t)W * L;
     if (P > 1024) return PS_EUNSUPPORTED;
     if (B == 0) return PS_OK;
@@ -341,17 +379,17 @@ extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const d
     int hs_log2 = 6;
     while ((1 << hs_log2) * 4 < 5 * P) ++hs_log2;      // table >= 1.25 P slots (load factor <= 0.8)
     WalkArgs a{rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff,
-               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, ids, counts, nvalid, hs_log2};
+               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2};
     const size_t lds = (size_t)WAVES_PER_BLOCK * (np * 64 + 3 * (1 << hs_log2) + BITMAP_WORDS) * sizeof(int32_t);
     int64_t grid = ps_cdiv(B, WAVES_PER_BLOCK);
-    if (grid > 256 * 32) grid = 256 * 32;
+    if (grid > (int64_t)1 << 30) grid = (int64_t)1 << 30;
     hipStream_t st = ps_stream(stream);
     switch (np) {
-        case 1: hipLaunchKernelGGL(walk_sample_kernel<1>, dim3((unsigned)grid), dim3(256), lds, st, a); break;
-        case 2: hipLaunchKernelGGL(walk_sample_kernel<2>, dim3((unsigned)grid), dim3(256), lds, st, a); break;
-        case 4: hipLaunchKernelGGL(walk_sample_kernel<4>, dim3((unsigned)grid), dim3(256), lds, st, a); break;
-        case 8: hipLaunchKernelGGL(walk_sample_kernel<8>, dim3((unsigned)grid), dim3(256), lds, st, a); break;
-        case 16: hipLaunchKernelGGL(walk_sample_kernel<16>, dim3((unsigned)grid), dim3(256), lds, st, a); break;
+        case 1: hipLaunchKernelGGL(walk_sample_kernel<1>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); break;
+        case 2: hipLaunchKernelGGL(walk_sample_kernel<2>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); break;
+        case 4: hipLaunchKernelGGL(walk_sample_kernel<4>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); break;
+        case 8: hipLaunchKernelGGL(walk_sample_kernel<8>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); break;
+        case 16: hipLaunchKernelGGL(walk_sample_kernel<16>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); break;
         default: return PS_EUNSUPPORTED;
     }
     PS_CHECK_LAUNCH();

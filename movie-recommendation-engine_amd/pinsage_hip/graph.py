@@ -52,6 +52,10 @@ class DeviceGraph:
             if E:
                 nv.call("ps_guide_build", nv.ptr(self.rowptr), nv.ptr(self.cdf), nv.i64(V), nv.ptr(self.nodeinfo),
                         nv.ptr(self.guide), nv.stream())
+            self.packed = torch.empty(((E + 7) // 8) * 128, dtype=torch.uint8, device=dev)
+            if E:
+                nv.call("ps_pack_edges", nv.ptr(self.col), nv.ptr(self.cdf), nv.ptr(self.guide), nv.i64(E),
+                        nv.ptr(self.packed), nv.stream())
             flags = torch.zeros(2, dtype=torch.int64, device=dev)
             nv.call("ps_graph_stats", nv.ptr(self.rowptr), nv.ptr(self.col), nv.i64(E), nv.i64(V), nv.ptr(flags),
                                       nv.stream())
@@ -62,4 +66,4 @@ class DeviceGraph:
         del ws
 
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.cdf, self.nodeinfo, self.guide))
+        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.cdf, self.nodeinfo, self.guide, self.packed))

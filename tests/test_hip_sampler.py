@@ -173,7 +173,8 @@ def test_guide_table_is_exact_on_skewed_weights():
     nodes = np.arange(700)
     a = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=True)
     b = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=False)
+    c = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=True, use_packed=False)
     ids, counts, nv, _, _, _ = co.walk_sample(cg, nodes, 20, 3, 100, philox=(5, 0), threads=8)
-    for x in (a, b):
+    for x in (a, b, c):
         assert np.array_equal(x.ids.cpu().numpy(), ids) and np.array_equal(x.counts.cpu().numpy(), counts)
         assert np.array_equal(x.nvalid.cpu().numpy(), nv)
