@@ -62,38 +62,40 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 constexpr int LIN_PROBES = 12;   // forward-scan probes after the guide lookup before falling back to bisection
 
 // (row start, out-degree) of node v: one 8-byte record when nodeinfo is present
-__device__ __forceinline__ void load_row(const int64_t *rowptr, const uint32_t *nodeinfo, int64_t v, int64_t &lo,
-                                         int64_t &hi) {
+typedef uint32_t eidx_t;   // edge index: E < 2^32 is enforced by ps_csr_build
+
+__device__ __forceinline__ void load_row(const int64_t *rowptr, const uint32_t *nodeinfo, int64_t v, eidx_t &lo,
+                                         eidx_t &hi) {
     if (nodeinfo) {
         const uint2 ni = reinterpret_cast<const uint2 *>(nodeinfo)[v];
         lo = ni.x;
         hi = lo + ni.y;
     } else {
-        lo = rowptr[v];
-        hi = rowptr[v + 1];
+        lo = (eidx_t)rowptr[v];
+        hi = (eidx_t)rowptr[v + 1];
     }
 }
 
 // Edge-record accessors: three arrays, or the interleaved 128-byte blocks [8 cdf | 8 col | 8 guide]
-__device__ __forceinline__ double edge_cdf(const double *cdf, const unsigned char *packed, int64_t e) {
-    return packed ? reinterpret_cast<const double *>(packed + (e >> 3) * 128)[e & 7] : cdf[e];
+__device__ __forceinline__ double edge_cdf(const double *cdf, const unsigned char *packed, eidx_t e) {
+    return packed ? reinterpret_cast<const double *>(packed + (size_t)(e >> 3) * 128)[e & 7] : cdf[e];
 }
-__device__ __forceinline__ int32_t edge_col(const int32_t *col, const unsigned char *packed, int64_t e) {
-    return packed ? reinterpret_cast<const int32_t *>(packed + (e >> 3) * 128 + 64)[e & 7] : col[e];
+__device__ __forceinline__ int32_t edge_col(const int32_t *col, const unsigned char *packed, eidx_t e) {
+    return packed ? reinterpret_cast<const int32_t *>(packed + (size_t)(e >> 3) * 128 + 64)[e & 7] : col[e];
 }
 
 // Start state of searchsorted(cdf[lo:hi], u, 'right'): with a guide table the search starts at the bucket
 // floor(u * deg) (guide = #{cdf <= (j-1)/deg} <= answer) and first scans forward; `n` counts probes.
-__device__ __forceinline__ void search_init(const int32_t *guide, const unsigned char *packed, int64_t lo, int64_t hi,
-                                            double u, int64_t &l, int &n) {
+__device__ __forceinline__ void search_init(const int32_t *guide, const unsigned char *packed, eidx_t lo, eidx_t hi,
+                                            double u, eidx_t &l, int &n) {
     l = lo;
     n = LIN_PROBES;
     if (guide || packed) {
         const uint32_t deg = (uint32_t)(hi - lo);
         uint32_t j = (uint32_t)(u * (double)deg);
         if (j >= deg) j = deg - 1;
-        const int64_t e = lo + j;
-        l = lo + (packed ? reinterpret_cast<const int32_t *>(packed + (e >> 3) * 128 + 96)[e & 7] : guide[e]);
+        const eidx_t e = lo + j;
+        l = lo + (eidx_t)(packed ? reinterpret_cast<const int32_t *>(packed + (size_t)(e >> 3) * 128 + 96)[e & 7] : guide[e]);
         n = 0;
     }
 }
@@ -119,10 +121,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
 
     for (int64_t i = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv; i < a.B; i += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
         const int64_t s = uniform_i64(a.starts[i]);
-        int64_t lo0 = 0, hi0 = 0;
+        eidx_t lo0 = 0, hi0 = 0;
         if (s >= 0 && s < a.V) {
-            lo0 = uniform_i64(a.rowptr[s]);
-            hi0 = uniform_i64(a.rowptr[s + 1]);
+            lo0 = (eidx_t)uniform_i64(a.rowptr[s]);
+            hi0 = (eidx_t)uniform_i64(a.rowptr[s + 1]);
         }
         int32_t *oid = a.ids + i * a.T;
         int32_t *ocn = a.counts + i * a.T;
@@ -143,9 +145,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             const int wA = w0 + lane, wB = w0 + 64 + lane;
             const bool actA = wA < a.W, actB = wB < a.W;
             bool aliveA = actA, aliveB = actB;
-            int64_t curA = s, curB = s;
+            int32_t curA = (int32_t)s, curB = (int32_t)s;
             for (int st = 0; st < a.L; ++st) {
-                int64_t loA = lo0, hiA = hi0, loB = lo0, hiB = hi0;
+                eidx_t loA = lo0, hiA = hi0, loB = lo0, hiB = hi0;
                 if (st > 0) {
                     if (aliveA) load_row(a.rowptr, a.nodeinfo, curA, loA, hiA);
                     if (aliveB) load_row(a.rowptr, a.nodeinfo, curB, loB, hiB);
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                     if (aliveA) uA = philox_uniform(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wA, (uint32_t)st, a.call);
                     if (aliveB) uB = philox_uniform(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wB, (uint32_t)st, a.call);
                 }
-                int64_t lA = loA, hA = loA, lB = loB, hB = loB;
+                eidx_t lA = loA, hA = loA, lB = loB, hB = loB;
                 int nA_ = 0, nB_ = 0;
                 if (aliveA) { search_init(a.guide, a.packed, loA, hiA, uA, lA, nA_); hA = hiA; }
                 if (aliveB) { search_init(a.guide, a.packed, loB, hiB, uB, lB, nB_); hB = hiB; }
@@ -172,8 +174,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                     const bool a_ = lA < hA, b_ = lB < hB;
                     if (!a_ && !b_) break;
                     const bool linA = nA_ < LIN_PROBES, linB = nB_ < LIN_PROBES;
-                    const int64_t mA = linA ? lA : lA + ((hA - lA) >> 1);
-                    const int64_t mB = linB ? lB : lB + ((hB - lB) >> 1);
+                    const eidx_t mA = linA ? lA : lA + ((hA - lA) >> 1);
+                    const eidx_t mB = linB ? lB : lB + ((hB - lB) >> 1);
                     const bool a2 = a_ && linA && (mA + 1 < hA), b2 = b_ && linB && (mB + 1 < hB);
                     const double cA0 = a_ ? edge_cdf(a.cdf, a.packed, mA) : 0.0;
                     const double cB0 = b_ ? edge_cdf(a.cdf, a.packed, mB) : 0.0;
@@ -280,7 +282,7 @@ __global__ void walk_paths_kernel(const int64_t *rowptr, const int32_t *col, con
         for (int st = 0; st < L; ++st) {
             int32_t nxt = -1;
             if (alive) {
-                int64_t lo, hi;
+                eidx_t lo, hi;
                 load_row(rowptr, nodeinfo, cur, lo, hi);
                 if (hi == lo) {
                     alive = false;
@@ -288,11 +290,11 @@ __global__ void walk_paths_kernel(const int64_t *rowptr, const int32_t *col, con
                     double u;
                     if (rng_mode == PS_RNG_STREAM) u = uniforms[ubase + st];
                     else u = philox_uniform(k0, k1, (uint32_t)s, (uint32_t)(walk_mod > 0 ? i % walk_mod : i), (uint32_t)st, call);
-                    int64_t l, h = hi;
+                    eidx_t l, h = hi;
                     int n;
                     search_init(guide, nullptr, lo, hi, u, l, n);
                     while (l < h) {
-                        const int64_t mid = (n < LIN_PROBES) ? l : l + ((h - l) >> 1);
+                        const eidx_t mid = (n < LIN_PROBES) ? l : l + ((h - l) >> 1);
                         if (cdf[mid] <= u) l = mid + 1; else h = mid;
                         ++n;
                     }
