@@ -11,10 +11,11 @@
 // accumulator per output (no split-K) -- bit-identical to `acc = fmaf(x[k], w[k], acc)`, which is
 // what the CPU oracle evaluates, so LSH sign decisions are bit-exact.
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN = (WM*TM*32) x (WN*TN*32), K step 32.
-// LDS image per operand row: [4 groups of 8 k][lane-half h][4] so that the lane (row i, half h)
+// Tiling: 256 threads = 4 waves; block tile BM x BN = (WM*TM*32) x (WN*TN*32), K step BK = 32 (BK = 16 was
+// measured 6 % slower: the 64 x 256 tile is register limited to 2 waves per SIMD, not LDS limited).
+// LDS image per operand row: [BK/8 groups of 8 k][lane-half h][4] so that the lane (row i, half h)
 // fetches its four k values of one group (k = 8g + 2t + h, t = 0..3) with a single ds_read_b128;
-// row stride 36 floats (144 B) keeps the b128 reads bank-conflict free.  The k-permutation is done
+// row stride BK+4 floats keeps the b128 reads bank-conflict free.  The k-permutation is done
 // in registers while staging (two float4 global loads per row-group), global loads for the next
 // K step are in flight while the current one is multiplied.
 #include "ps_common.h"
@@ -23,8 +24,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = 36;
 
 struct GemmArgs {
     const float *x;  int64_t M; int K;  const float *W;  int ldw;
@@ -46,11 +45,12 @@ __device__ __forceinline__ void load8(const float *base, bool row_ok, int k, int
     }
 }
 
-template <int WM, int WN, int TM, int TN, int EPI>
+template <int WM, int WN, int TM, int TN, int BK, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_ITEMS = BM * 4 / 256, B_ITEMS = BN * 4 / 256;   // (row, group) items per thread
-    static_assert(BM * 4 % 256 == 0 && BN * 4 % 256 == 0, "tile/thread mismatch");
+    constexpr int GRP = BK / 8;                        // 8-k groups per row
+    constexpr int LDS_STRIDE = BK + 4;                 // floats; 144 B (BK 32) / 80 B (BK 16): b128 reads conflict free
+    constexpr int A_ITEMS = (BM * GRP + 255) / 256, B_ITEMS = (BN * GRP + 255) / 256;   // (row, group) items per thread
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_STRIDE + BM * WN];
     float *sA = smem, *sB = smem + BM * LDS_STRIDE, *sRed = smem + (BM + BN) * LDS_STRIDE;
 
@@ -81,28 +81,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         auto fetch = [&](int k0) {
 #pragma unroll
             for (int q = 0; q < A_ITEMS; ++q) {
-                const int it = tid + 256 * q, row = it >> 2, grp = it & 3;
+                const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
                 const int64_t m = m0 + row;
-                load8(X + m * K, m < g.M, k0 + grp * 8, K, vecA, ra[q]);
+                if (it < BM * GRP) load8(X + m * K, m < g.M, k0 + grp * 8, K, vecA, ra[q]);
             }
 #pragma unroll
             for (int q = 0; q < B_ITEMS; ++q) {
-                const int it = tid + 256 * q, row = it >> 2, grp = it & 3;
+                const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
                 const int n = n0 + row;
-                load8(Wp + (int64_t)n * ldw, n < g.N, k0 + grp * 8, K, vecB, rb[q]);
+                if (it < BN * GRP) load8(Wp + (int64_t)n * ldw, n < g.N, k0 + grp * 8, K, vecB, rb[q]);
             }
         };
         auto stash = [&]() {
 #pragma unroll
             for (int q = 0; q < A_ITEMS; ++q) {
-                const int it = tid + 256 * q, row = it >> 2, grp = it & 3;
+                const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
+                if (it >= BM * GRP) continue;
                 float *d = sA + row * LDS_STRIDE + grp * 8;
                 *reinterpret_cast<float4 *>(d) = make_float4(ra[q][0], ra[q][2], ra[q][4], ra[q][6]);
                 *reinterpret_cast<float4 *>(d + 4) = make_float4(ra[q][1], ra[q][3], ra[q][5], ra[q][7]);
             }
 #pragma unroll
             for (int q = 0; q < B_ITEMS; ++q) {
-                const int it = tid + 256 * q, row = it >> 2, grp = it & 3;
+                const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
+                if (it >= BN * GRP) continue;
                 float *d = sB + row * LDS_STRIDE + grp * 8;
                 *reinterpret_cast<float4 *>(d) = make_float4(rb[q][0], rb[q][2], rb[q][4], rb[q][6]);
                 *reinterpret_cast<float4 *>(d + 4) = make_float4(rb[q][1], rb[q][3], rb[q][5], rb[q][7]);
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             __syncthreads();
             if (k0 + BK < K) fetch(k0 + BK);
 #pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
+            for (int grp = 0; grp < GRP; ++grp) {
                 float4 fa[TM], fb[TN];
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
@@ -237,13 +239,13 @@ template <int EPI>
 int launch_gemm(const GemmArgs &g, hipStream_t st) {
     if (g.N <= 64) {
         dim3 grid((unsigned)ps_cdiv(g.M, 64), 1);
-        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 1, EPI>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 1, 32, EPI>), grid, dim3(256), 0, st, g);
     } else if (g.N <= 128) {
         dim3 grid((unsigned)ps_cdiv(g.M, 64), 1);
-        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, EPI>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, EPI>), grid, dim3(256), 0, st, g);
     } else {
         dim3 grid((unsigned)ps_cdiv(g.M, 64), (unsigned)ps_cdiv(g.N, 256));
-        hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 2, 2, EPI>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 2, 2, 32, EPI>), grid, dim3(256), 0, st, g);
     }
     PS_CHECK_LAUNCH();
     return PS_OK;

@@ -1,0 +1,152 @@
+"""BASELINE-size runs (SYN-25M: 59 047 items, 162 541 users, 50 M directed edges) checked through
+size-independent properties -- the oracle cannot finish these sizes in seconds, so: structural invariants of
+the CSR/CDF, sampler invariants + determinism + batching/shard invariance, encode->search round trips,
+sharded search == unsharded search."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    from pinsage_hip import synth
+    from pinsage_hip.graph import DeviceGraph
+    dev = torch.device("cuda")
+    ei, ew = synth.bipartite_ratings(**synth.ML25M, device=dev)
+    g = DeviceGraph(ei, ew)
+    return g, ei, ew
+
+
+def test_graph_invariants_full_size(big):
+    g, ei, ew = big
+    M = 59047
+    assert g.V == 59047 + 162541 and g.E == ei.size(1) == 2 * 25000095
+    deg = g.rowptr[1:] - g.rowptr[:-1]
+    assert int(deg.min()) >= 1 and not g.has_reachable_sink and g.max_degree == int(deg.max())
+    assert torch.equal(deg, torch.bincount(ei[0], minlength=g.V))
+    # bipartite: item rows point at users and vice versa
+    row_of_edge = torch.repeat_interleave(torch.arange(g.V, device=deg.device), deg)
+    assert bool(((row_of_edge < M) != (g.col.long() < M)).all())
+    # every row's CDF is non-decreasing, ends at exactly 1.0, first entry > 0
+    last = g.cdf[(g.rowptr[1:] - 1)]
+    assert bool((last == 1.0).all())
+    d = g.cdf[1:] - g.cdf[:-1]
+    is_row_start = torch.zeros(g.E, dtype=torch.bool, device=d.device)
+    is_row_start[g.rowptr[:-1]] = True
+    assert bool((d[~is_row_start[1:]] >= 0).all()) and bool((g.cdf[g.rowptr[:-1]] > 0).all())
+    # guide: a valid lower bound of every bucket (start <= searchsorted(cdf, j/deg))
+    e = torch.randint(0, g.E, (200000,), device=d.device)
+    row = row_of_edge[e]
+    lo = g.rowptr[row]
+    j = e - lo
+    start = lo + g.guide[e].long()
+    t = j.double() / deg[row].double()
+    assert bool((start >= lo).all()) and bool((start < g.rowptr[row + 1]).all())
+    prev_ok = (start == lo) | (g.cdf[(start - 1).clamp(min=0)] <= t)
+    assert bool(prev_ok.all())
+
+
+def test_sampler_properties_full_size(big):
+    from pinsage_hip import sampling
+    g, ei, ew = big
+    M, W, L, T = 59047, 100, 2, 10
+    nodes = torch.arange(M, device=g.device)
+    a = sampling.walk_sample(g, nodes, T, W, L, rng="philox", seed=42, call=3)
+    b = sampling.walk_sample(g, nodes, T, W, L, rng="philox", seed=42, call=3)
+    assert torch.equal(a.ids, b.ids) and torch.equal(a.counts, b.counts)            # deterministic
+    # batching / shard invariance: any slice of start nodes gives the same rows
+    for lo, hi in ((0, 1024), (30000, 37381), (59000, 59047)):
+        s = sampling.walk_sample(g, nodes[lo:hi], T, W, L, rng="philox", seed=42, call=3)
+        assert torch.equal(s.ids, a.ids[lo:hi]) and torch.equal(s.counts, a.counts[lo:hi])
+    nv = a.nvalid.long()
+    ar = torch.arange(T, device=g.device)[None, :]
+    valid = ar < nv[:, None]
+    assert bool((nv == T).all())                                   # 200 visits over >= 20-degree rows: always >= T distinct
+    assert bool((a.ids[valid] >= 0).all()) and bool((a.ids[~valid] == -1).all())
+    c = a.counts.long()
+    assert bool((c[valid] >= 1).all()) and bool((c.sum(1) <= W * L).all())
+    assert bool((c[:, :-1] >= c[:, 1:]).all())                     # sorted by visit count, descending
+    # no duplicate ids inside a row
+    srt = torch.sort(a.ids, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    # visited nodes are within 2 hops: step-1 nodes are users adjacent to the start item
+    users_first = a.ids >= M
+    i, jx = torch.nonzero(users_first & valid, as_tuple=True)
+    pick = torch.randint(0, i.numel(), (20000,), device=g.device)
+    si, su = i[pick], a.ids[i[pick], jx[pick]].long()
+    # (item si, user su) must be an edge: binary search the item's row for su is not possible (rows keep edge
+    # order), so test membership through the user's row length > 0 and the reverse edge count > 0
+    lo, hi = g.rowptr[si], g.rowptr[si + 1]
+    found = torch.zeros_like(si, dtype=torch.bool)
+    for k in range(0, 64):                                          # probe the first 64 entries + hub rows skipped
+        idx = (lo + k).clamp(max=g.E - 1)
+        found |= (g.col[idx].long() == su) & (lo + k < hi)
+    small = (hi - lo) <= 64
+    assert bool(found[small].all())
+    # different call index -> different samples (fresh draws per layer)
+    d = sampling.walk_sample(g, nodes, T, W, L, rng="philox", seed=42, call=4)
+    assert not torch.equal(d.ids, a.ids)
+    # numpy-stream mode at full size: device MT19937 stream == numpy's, same results for both uniform sources
+    np.random.seed(9)
+    ref_u = np.random.random_sample(4096 * W * L)
+    np.random.seed(9)
+    from pinsage_hip import dense
+    u = dense.mt19937_random_sample(4096 * W * L, g.device)
+    assert np.array_equal(u.cpu().numpy(), ref_u)
+    x = sampling.walk_sample(g, nodes[:4096], T, W, L, rng="numpy", uniforms=u)
+    y = sampling.walk_sample(g, nodes[:4096], T, W, L, rng="numpy", uniforms=torch.from_numpy(ref_u).to(g.device), use_guide=False)
+    assert torch.equal(x.ids, y.ids) and torch.equal(x.counts, y.counts)
+
+
+def test_lsh_roundtrip_and_sharded_search_full_size():
+    from pinsage_hip import dense
+    from utils.nearest_neighbors import lsh_rotation_matrix
+    dev = torch.device("cuda")
+    M, D, nbits, k = 59047, 256, 512, 11
+    g = torch.Generator(device=dev).manual_seed(0)
+    emb = torch.nn.functional.normalize(torch.randn(M, D, generator=g, device=dev), dim=1)
+    A = torch.from_numpy(lsh_rotation_matrix(D, nbits)).to(dev)
+    codes = dense.lsh_encode(emb, A)
+    assert codes.shape == (M, nbits // 8)
+    # linearity of the projection sign: encode(-x) is the bitwise complement wherever x.a != 0
+    neg = dense.lsh_encode(-emb[:4096], A)
+    assert int(torch.bitwise_and(neg, codes[:4096]).ne(0).sum()) < 16            # only exact zeros may share bits
+    q = torch.arange(0, M, 7, device=dev)[:8192]
+    dist, ids = dense.hamming_topk(codes[q], codes, k)
+    assert bool((ids[:, 0] == q).all()) and bool((dist[:, 0] == 0).all())        # an item is its own nearest code
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())                              # ascending distances
+    same = dist[:, 1:] == dist[:, :-1]
+    assert bool((ids[:, 1:][same] > ids[:, :-1][same]).all())                     # ties by ascending id
+    # distances are the true Hamming distances of the returned ids
+    x = torch.bitwise_xor(codes[q][:, None, :], codes[ids])
+    true = torch.zeros_like(dist)
+    for b in range(8):
+        true += ((x >> b) & 1).sum(dim=2).int()
+    assert torch.equal(true, dist)
+    # 8 shards + merge == unsharded
+    chunk = (M + 7) // 8
+    parts = [dense.hamming_topk(codes[q], codes[s:s + chunk], k, id_offset=s) for s in range(0, M, chunk)]
+    dm, im = dense.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(dm, dist) and torch.equal(im, ids)
+
+
+def test_embeddings_full_size_unit_norm_and_shard_invariance(big):
+    from pinsage_hip.shard import ShardedPinSage
+    from utils.random_walk import RandomWalkSampler
+    from model.pinsage import PinSage
+    g, ei, ew = big
+    M = 59047
+    torch.manual_seed(2)
+    model = PinSage(128, 256, 256, 2).to(g.device).eval()
+    x = torch.randn(M, 128, device=g.device)
+    smp = RandomWalkSampler.from_graph(g, 2, 100, rng="philox", seed=42)
+    with torch.no_grad():
+        e1 = model.get_embeddings(x, smp, 10)
+        smp._calls = 0
+        params = {k: v.detach() for k, v in model.state_dict().items()}
+        e2 = ShardedPinSage(params, 2, smp, M).embed(x, 10)
+    assert torch.equal(e1, e2)                                                    # class API == sharded pipeline (1 rank)
+    np.testing.assert_allclose(e1.norm(dim=1).cpu().numpy(), 1.0, rtol=0, atol=1e-5)
+    assert bool(torch.isfinite(e1).all())
