@@ -45,7 +45,10 @@ __device__ __forceinline__ void load8(const float *base, bool row_ok, int k, int
     }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int EPI>
+// FAST: every operand is 16-B aligned with K % BK == 0 -> unconditional float4 loads (rows past the end are
+// clamped to the last valid row; their results are never stored), so nothing branches or waits inside the
+// fetch and the loads stay in flight under the MFMAs.  The general variant predicates every element.
+template <int WM, int WN, int TM, int TN, int BK, int EPI, bool FAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int GRP = BK / 8;                        // 8-k groups per row
@@ -83,20 +86,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int q = 0; q < A_ITEMS; ++q) {
                 const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
                 const int64_t m = m0 + row;
-                if (it < BM * GRP) load8(X + m * K, m < g.M, k0 + grp * 8, K, vecA, ra[q]);
+                if (FAST) {
+                    static_assert(!FAST || (BM * GRP) % 256 == 0, "FAST needs whole items per thread");
+                    {
+                        const float *src = X + (m < g.M ? m : g.M - 1) * K + k0 + grp * 8;
+                        const float4 a = *reinterpret_cast<const float4 *>(src);
+                        const float4 b = *reinterpret_cast<const float4 *>(src + 4);
+                        ra[q][0] = a.x; ra[q][1] = a.y; ra[q][2] = a.z; ra[q][3] = a.w;
+                        ra[q][4] = b.x; ra[q][5] = b.y; ra[q][6] = b.z; ra[q][7] = b.w;
+                    }
+                } else if (it < BM * GRP) load8(X + m * K, m < g.M, k0 + grp * 8, K, vecA, ra[q]);
             }
 #pragma unroll
             for (int q = 0; q < B_ITEMS; ++q) {
                 const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
                 const int n = n0 + row;
-                if (it < BN * GRP) load8(Wp + (int64_t)n * ldw, n < g.N, k0 + grp * 8, K, vecB, rb[q]);
+                if (FAST) {
+                    static_assert(!FAST || (BN * GRP) % 256 == 0, "FAST needs whole items per thread");
+                    {
+                        const float *src = Wp + (int64_t)(n < g.N ? n : g.N - 1) * ldw + k0 + grp * 8;
+                        const float4 a = *reinterpret_cast<const float4 *>(src);
+                        const float4 b = *reinterpret_cast<const float4 *>(src + 4);
+                        rb[q][0] = a.x; rb[q][1] = a.y; rb[q][2] = a.z; rb[q][3] = a.w;
+                        rb[q][4] = b.x; rb[q][5] = b.y; rb[q][6] = b.z; rb[q][7] = b.w;
+                    }
+                } else if (it < BN * GRP) load8(Wp + (int64_t)n * ldw, n < g.N, k0 + grp * 8, K, vecB, rb[q]);
             }
         };
         auto stash = [&]() {
 #pragma unroll
             for (int q = 0; q < A_ITEMS; ++q) {
                 const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
-                if (it >= BM * GRP) continue;
+                if (!FAST && it >= BM * GRP) continue;
                 float *d = sA + row * LDS_STRIDE + grp * 8;
                 *reinterpret_cast<float4 *>(d) = make_float4(ra[q][0], ra[q][2], ra[q][4], ra[q][6]);
                 *reinterpret_cast<float4 *>(d + 4) = make_float4(ra[q][1], ra[q][3], ra[q][5], ra[q][7]);
@@ -104,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int q = 0; q < B_ITEMS; ++q) {
                 const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
-                if (it >= BN * GRP) continue;
+                if (!FAST && it >= BN * GRP) continue;
                 float *d = sB + row * LDS_STRIDE + grp * 8;
                 *reinterpret_cast<float4 *>(d) = make_float4(rb[q][0], rb[q][2], rb[q][4], rb[q][6]);
                 *reinterpret_cast<float4 *>(d + 4) = make_float4(rb[q][1], rb[q][3], rb[q][5], rb[q][7]);
@@ -207,6 +228,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                 for (int b = 0; b < TN; ++b) acc[a][b][r] = acc[a][b][r] / nrm;
             }
     }
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);     // block-uniform: no per-element guards
+    if (interior) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *dst = g.y + (m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * g.N + n0 + wn * TN * 32 + li;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) dst[b * 32] = acc[a][b][r];
+            }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -235,20 +268,31 @@ __global__ void l2norm_rows_kernel(float *y, int64_t M, int N) {   // N > 256 on
     }
 }
 
-template <int EPI>
-int launch_gemm(const GemmArgs &g, hipStream_t st) {
+template <int EPI, bool FAST>
+int launch_gemm_v(const GemmArgs &g, hipStream_t st) {
     if (g.N <= 64) {
         dim3 grid((unsigned)ps_cdiv(g.M, 64), 1);
-        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 1, 32, EPI>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 1, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
     } else if (g.N <= 128) {
         dim3 grid((unsigned)ps_cdiv(g.M, 64), 1);
-        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, EPI>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
     } else {
         dim3 grid((unsigned)ps_cdiv(g.M, 64), (unsigned)ps_cdiv(g.N, 256));
-        hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 2, 2, 32, EPI>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 2, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
     }
     PS_CHECK_LAUNCH();
     return PS_OK;
+}
+
+bool aligned_operand(const float *p, int K, int ld) {
+    return p == nullptr || (reinterpret_cast<size_t>(p) % 16 == 0 && K % 32 == 0 && ld % 4 == 0);
+}
+
+template <int EPI>
+int launch_gemm(const GemmArgs &g, hipStream_t st) {
+    const bool fast = aligned_operand(g.x, g.K, g.K) && aligned_operand(g.W, g.K, g.ldw) &&
+                      (g.x2 == nullptr || (aligned_operand(g.x2, g.K2, g.K2) && aligned_operand(g.W2, g.K2, g.ldw2)));
+    return fast ? launch_gemm_v<EPI, true>(g, st) : launch_gemm_v<EPI, false>(g, st);
 }
 
 }  // namespace
