@@ -156,6 +156,16 @@ size_t ps_dot_topk_workspace_bytes(int64_t nq, int64_t N, int D, int k);
 int ps_dot_topk(const float *E, int64_t N, int D, const int64_t *qidx, int64_t nq, int k, int exclude_self,
                 float *vals, int64_t *ids, void *workspace, size_t workspace_bytes, ps_stream_t stream);
 
+/* ---- next row: exact L2 / IVF search behind WeakANDIndex and benchmark_search_methods
+ * (utils/nearest_neighbors.py:70-139, 176: faiss.IndexFlatL2 / faiss.IndexIVFFlat).
+ * dist(q, x) = |q|^2 + |x|^2 - 2 q.x in fp32; k smallest by (distance, id), ascending; dist float[nq,k]
+ * (FLT_MAX pad), ids int64[nq,k] (-1 pad).  With assign int32[N] (inverted-list id of every item) and
+ * probe uint32[nq, words] (bit l set = list l is probed by that query) only probed lists are visible. */
+size_t ps_l2_topk_workspace_bytes(int64_t nq, int64_t N, int D, int k);
+int ps_l2_topk(const float *X, int64_t N, int D, const float *Q, int64_t nq, int k, const int32_t *assign,
+               const uint32_t *probe, int words, float *dist, int64_t *ids, void *workspace,
+               size_t workspace_bytes, ps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,8 +32,14 @@ __device__ __forceinline__ float key_value(uint32_t kk) {
     return __uint_as_float(b);
 }
 
+// MODE 0: largest similarity first (exact inner-product search).  MODE 1: smallest L2 distance first,
+// dist = |q|^2 + |x|^2 - 2 q.x, optionally restricted to the items whose inverted list (assign) is probed.
+template <int MODE>
 __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__ sims, int64_t N, int64_t rows,
                                                        const int64_t *__restrict__ qidx, int exclude_self, int k,
+                                                       const float *__restrict__ qn, const float *__restrict__ xn,
+                                                       const int32_t *__restrict__ assign,
+                                                       const uint32_t *__restrict__ probe, int words,
                                                        float *__restrict__ vals, int64_t *__restrict__ ids) {
     extern __shared__ uint64_t skeys[];   // [4 waves][k][64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -45,10 +51,18 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
     for (int p = 0; p < k; ++p) col[p * 64] = EMPTY_KEY;
     uint64_t worst = EMPTY_KEY;
     int filled = 0;
+    const float qnr = (MODE == 1) ? qn[row] : 0.f;
     for (int64_t j = lane; j < N; j += 64) {
         float v = s[j];
+        if (MODE == 1) {
+            if (assign) {
+                const int32_t a = assign[j];
+                if (!((probe[row * words + (a >> 5)] >> (a & 31)) & 1u)) continue;   // list not probed
+            }
+            v = (qnr + xn[j]) - 2.f * v;
+        }
         if (j == self) v = -INFINITY;
-        const uint64_t key = ((uint64_t)desc_key(v) << 32) | (uint32_t)j;
+        const uint64_t key = ((uint64_t)(MODE == 1 ? ~desc_key(v) : desc_key(v)) << 32) | (uint32_t)j;
         if (key < worst) {
             int p = filled < k ? filled : k - 1;
             while (p > 0 && col[(p - 1) * 64] > key) { col[p * 64] = col[(p - 1) * 64]; --p; }
@@ -70,9 +84,22 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
         }
         if (mine == best && best != EMPTY_KEY) ++head;      // keys are unique (id in the low word)
         if (lane == 0) {
-            vals[row * k + r] = best != EMPTY_KEY ? key_value((uint32_t)(best >> 32)) : -INFINITY;
+            const uint32_t kk = (uint32_t)(best >> 32);
+            vals[row * k + r] = best != EMPTY_KEY ? key_value(MODE == 1 ? ~kk : kk) : (MODE == 1 ? 3.4028234663852886e38f : -INFINITY);
             ids[row * k + r] = best != EMPTY_KEY ? (int64_t)(uint32_t)best : -1;
         }
+    }
+}
+
+__global__ void row_sqnorm_kernel(const float *__restrict__ x, int64_t n, int D, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nw) {
+        float ss = 0.f;
+        for (int d = lane; d < D; d += 64) ss = fmaf(x[i * D + d], x[i * D + d], ss);
+        ss = ps_wave_sum_f32(ss);
+        if (lane == 0) out[i] = ss;
     }
 }
 
@@ -111,8 +138,51 @@ extern "C" int ps_dot_topk(const float *E, int64_t N, int D, const int64_t *qidx
         PS_CHECK_LAUNCH();
         const int rc = ps_linear(Q, rows, D, E, D, nullptr, (int)N, nullptr, 0, nullptr, 0, 0, sims, stream);
         if (rc != PS_OK) return rc;
-        hipLaunchKernelGGL(row_topk_kernel, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), lds, st, sims, N, rows,
-                           qidx + q0, exclude_self, k, vals + q0 * k, ids + q0 * k);
+        hipLaunchKernelGGL(row_topk_kernel<0>, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), lds, st, sims, N, rows,
+                           qidx + q0, exclude_self, k, (const float *)nullptr, (const float *)nullptr,
+                           (const int32_t *)nullptr, (const uint32_t *)nullptr, 0, vals + q0 * k, ids + q0 * k);
+        PS_CHECK_LAUNCH();
+    }
+    return PS_OK;
+}
+
+extern "C" size_t ps_l2_topk_workspace_bytes(int64_t nq, int64_t N, int D, int k) {
+    if (nq <= 0 || N <= 0) return 256;
+    const int64_t c = chunk_rows(nq, N);
+    return (size_t)c * N * sizeof(float) + (size_t)(N + nq) * sizeof(float) + 2048;
+}
+
+extern "C" int ps_l2_topk(const float *X, int64_t N, int D, const float *Q, int64_t nq, int k, const int32_t *assign,
+                          const uint32_t *probe, int words, float *dist, int64_t *ids, void *workspace,
+                          size_t workspace_bytes, ps_stream_t stream) {
+    if (N < 0 || D <= 0 || nq < 0 || k <= 0) return PS_EINVAL;
+    if (k > 160 || N >= ((int64_t)1 << 32)) return PS_EUNSUPPORTED;
+    if (nq == 0) return PS_OK;
+    if (!X || !Q || !dist || !ids || !workspace) return PS_EINVAL;
+    if ((assign == nullptr) != (probe == nullptr) || (probe && words <= 0)) return PS_EINVAL;
+    if (workspace_bytes < ps_l2_topk_workspace_bytes(nq, N, D, k)) return PS_EWORKSPACE;
+    hipStream_t st = ps_stream(stream);
+    const int64_t c = chunk_rows(nq, N);
+    char *base = reinterpret_cast<char *>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
+    float *sims = reinterpret_cast<float *>(base);
+    float *xn = reinterpret_cast<float *>(base + ((size_t)c * N * sizeof(float) + 255) / 256 * 256);
+    float *qn = xn + (N + 63) / 64 * 64;
+    int64_t g = ps_cdiv(N, 4);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)g), dim3(256), 0, st, X, N, D, xn);
+    PS_CHECK_LAUNCH();
+    g = ps_cdiv(nq, 4);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)g), dim3(256), 0, st, Q, nq, D, qn);
+    PS_CHECK_LAUNCH();
+    const size_t lds = (size_t)4 * k * 64 * sizeof(uint64_t);
+    for (int64_t q0 = 0; q0 < nq; q0 += c) {
+        const int64_t rows = (nq - q0) < c ? (nq - q0) : c;
+        const int rc = ps_linear(Q + q0 * D, rows, D, X, D, nullptr, (int)N, nullptr, 0, nullptr, 0, 0, sims, stream);
+        if (rc != PS_OK) return rc;
+        hipLaunchKernelGGL(row_topk_kernel<1>, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), lds, st, sims, N, rows,
+                           (const int64_t *)nullptr, 0, k, qn + q0, xn, assign, probe ? probe + q0 * words : nullptr, words,
+                           dist + q0 * k, ids + q0 * k);
         PS_CHECK_LAUNCH();
     }
     return PS_OK;

@@ -120,6 +120,24 @@ def dot_topk(E, qidx, k, exclude_self=True):
     return vals, ids
 
 
+def l2_topk(X, Q, k, assign=None, probe=None):
+    """k nearest by squared L2 (IndexFlatL2 / IndexIVFFlat scan): -> (dist fp32[nq,k], ids int64[nq,k])."""
+    X = X.contiguous()
+    Q = Q.to(X.device).contiguous()
+    N, D = int(X.size(0)), int(X.size(1))
+    nq = int(Q.size(0))
+    dist = torch.empty((nq, k), dtype=torch.float32, device=X.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=X.device)
+    L = nv.lib()
+    wsb = int(L.ps_l2_topk_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(D), nv.i32(k)))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=X.device)
+    words = int(probe.size(1)) if probe is not None else 0
+    with torch.cuda.device(X.device):
+        nv.call("ps_l2_topk", nv.ptr(X), nv.i64(N), nv.i32(D), nv.ptr(Q), nv.i64(nq), nv.i32(k), nv.ptr(assign),
+                nv.ptr(probe), nv.i32(words), nv.ptr(dist), nv.ptr(ids), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
+    return dist, ids
+
+
 def mt19937_random_sample(n, device):
     """n doubles of the process-global numpy legacy stream generated ON THE DEVICE; the global
     np.random state is advanced exactly as `np.random.random_sample(n)` would (reference
