@@ -88,9 +88,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    # PS_BENCH_BACKEND=gloo + PS_BENCH_SHARE_GPU=1: rehearsal of the N > 1 path on a one-GPU box (all ranks on
+    # cuda:0, collectives staged through the host); the driver's runs use RCCL, one GPU per rank.
+    backend = os.environ.get("PS_BENCH_BACKEND", "nccl")
+    if os.environ.get("PS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -179,7 +187,7 @@ def main():
         elapsed_instr = time.perf_counter() - t1
         nv.set_timer(None)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     for (e0, e1, e2, e3) in recs:

@@ -36,8 +36,11 @@ def all_gather_rows(t, chunk, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
     world = dist.get_world_size(group)
-    pad = torch.zeros((chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[: t.size(0)] = t
+    if t.size(0) == chunk and t.is_contiguous():
+        pad = t                                          # full shard (all ranks but possibly the last): no copy
+    else:
+        pad = torch.zeros((chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.size(0)] = t
     stage_cpu = _backend(group) == "gloo" and pad.is_cuda       # gloo has no CUDA all_gather
     src = pad.cpu() if stage_cpu else pad
     out = torch.empty((world * chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
