@@ -129,7 +129,8 @@ def main():
     A = torch.from_numpy(lsh_rotation_matrix(D, nbits)).to(dev)
     pipe = ShardedPinSage(params, LAYERS, sampler, M)
     x_loc = x_full[pipe.lo:pipe.hi].to(dev).contiguous()
-    del x_full
+    x_rep = x_full.to(dev).contiguous() if world > 1 else None      # replicated features (30 MB): lets every rank
+    del x_full                                                       # recompute layer-0 rows instead of gathering them
     nq_local = max(1, a.queries // world)
     nq = nq_local * world
 
@@ -141,7 +142,7 @@ def main():
             np.random.seed(42)
         e0, e1, e2, e3 = ev(), ev(), ev(), ev()
         e0.record()
-        emb = pipe.embed(x_loc, T)
+        emb = pipe.embed(x_loc, T, x_full=x_rep)
         e1.record()
         pipe.build_index(emb, A)
         e2.record()

@@ -31,21 +31,42 @@ def _backend(group):
     return dist.get_backend(group) if dist.is_initialized() else None
 
 
-def all_gather_rows(t, chunk, group=None):
-    """[n_local, ...] (n_local <= chunk) -> [world * chunk, ...]; rank r's rows start at r * chunk."""
+class _Gather:
+    """Handle of an all-gather of row shards; `.wait()` returns [world * chunk, ...]."""
+
+    def __init__(self, out, work=None, dev=None):
+        self.out, self.work, self.dev = out, work, dev
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        return self.out if self.dev is None else self.out.to(self.dev)
+
+
+def all_gather_rows_async(t, chunk, group=None):
+    """[n_local, ...] (n_local <= chunk) -> handle; rank r's rows start at r * chunk.  With RCCL the collective
+    runs asynchronously on its own stream (overlaps kernels enqueued afterwards); gloo has no CUDA all_gather,
+    so it is staged through the host synchronously (tests / rehearsal only)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return t
+        return _Gather(t)
     world = dist.get_world_size(group)
     if t.size(0) == chunk and t.is_contiguous():
         pad = t                                          # full shard (all ranks but possibly the last): no copy
     else:
         pad = torch.zeros((chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[: t.size(0)] = t
-    stage_cpu = _backend(group) == "gloo" and pad.is_cuda       # gloo has no CUDA all_gather
-    src = pad.cpu() if stage_cpu else pad
-    out = torch.empty((world * chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
-    dist.all_gather_into_tensor(out, src.contiguous(), group=group)
-    return out.to(t.device) if stage_cpu else out
+    if _backend(group) == "gloo" and pad.is_cuda:
+        src = pad.cpu()
+        out = torch.empty((world * chunk,) + tuple(t.shape[1:]), dtype=t.dtype)
+        dist.all_gather_into_tensor(out, src.contiguous(), group=group)
+        return _Gather(out, dev=t.device)
+    out = torch.empty((world * chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=pad.device)
+    work = dist.all_gather_into_tensor(out, pad.contiguous(), group=group, async_op=True)
+    return _Gather(out, work)
+
+
+def all_gather_rows(t, chunk, group=None):
+    return all_gather_rows_async(t, chunk, group).wait()
 
 
 class HipOps:
@@ -85,21 +106,34 @@ class ShardedPinSage:
         self.lo, self.hi, self.chunk = shard_range(self.M, self.rank, self.world)
 
     # -- embeddings: PinSage.get_embeddings (model/pinsage.py:253-280) for the local item range ------
-    def embed(self, x_local, T):
+    def embed(self, x_local, T, x_full=None):
+        """x_local: this rank's feature rows.  x_full (optional, replicated [M, F] features): layer-0 hidden
+        rows of ALL items are then recomputed locally (one small GEMM) instead of all-gathered."""
         ops, P = self.ops, self.P
         dev = x_local.device
         nodes = torch.arange(self.lo, self.hi, dtype=torch.int64, device=dev)
-        # fresh neighbour samples per layer, drawn in the reference's order (:271-275); no communication
-        batches = [ops.sample(self.sampler, nodes, T) for _ in range(self.num_layers)]
-        h = ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
+        # fresh neighbour samples per layer, drawn in the reference's order (:271-275); no communication.
+        # Layer i+1's sampling and lin_self are enqueued while layer i's hidden rows are being all-gathered.
+        batch = ops.sample(self.sampler, nodes, T)
+        if x_full is not None and self.world > 1:
+            h_all = ops.linear(x_full, P["input_proj.weight"], P["input_proj.bias"], relu=True)
+            h = h_all[self.lo:self.hi]
+            pending = _Gather(h_all)
+        else:
+            h = ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
+            pending = all_gather_rows_async(h, self.chunk, self.group)
         for i in range(self.num_layers):
-            h_full = all_gather_rows(h, self.chunk, self.group)          # the per-layer exchange
-            h_neigh = ops.pool(h_full, batches[i], self.M - 1)
+            next_batch = ops.sample(self.sampler, nodes, T) if i + 1 < self.num_layers else None
             H = h.size(1)
             h_self = ops.linear(h, P[f"convs.{i}.lin_self.weight"], P[f"convs.{i}.lin_self.bias"])
+            h_full = pending.wait()                                          # the per-layer exchange
+            h_neigh = ops.pool(h_full, batch, self.M - 1)
             Wu = P[f"convs.{i}.lin_update.weight"]
             h = ops.linear(h_self, Wu[:, :H], P[f"convs.{i}.lin_update.bias"], x2=h_neigh, W2=Wu[:, H:],
                            relu=True, l2norm=True)
+            if next_batch is not None:
+                pending = all_gather_rows_async(h, self.chunk, self.group)
+                batch = next_batch
         return ops.linear(h, P["output_proj.weight"], P["output_proj.bias"], l2norm=True)
 
     # -- LSH: LSHIndex.build / .search (utils/nearest_neighbors.py:28-68) over code shards -------------
@@ -119,6 +153,6 @@ class ShardedPinSage:
         if self.world == 1:
             return d, i
         nq = qc_all.size(0)
-        d_all = all_gather_rows(d.reshape(1, nq, k), 1, self.group)
-        i_all = all_gather_rows(i.reshape(1, nq, k), 1, self.group)
-        return ops.topk_merge(d_all, i_all)
+        both = torch.stack([d.to(torch.int64), i]).reshape(1, 2, nq, k)       # one collective for (dist, id)
+        both_all = all_gather_rows(both, 1, self.group)                       # [P, 2, nq, k]
+        return ops.topk_merge(both_all[:, 0].to(torch.int32).contiguous(), both_all[:, 1].contiguous())

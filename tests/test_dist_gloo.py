@@ -88,7 +88,9 @@ def _run(rank, world, port, out):
         from pinsage_hip.shard import ShardedPinSage, all_gather_rows
         cg, params, x, A = _setup()
         pipe = ShardedPinSage(params, 2, _Sampler(cg, 77), M, ops=OracleOps())
-        emb = pipe.embed(x[pipe.lo:pipe.hi], T)
+        emb = pipe.embed(x[pipe.lo:pipe.hi], T, x_full=x if rank == 0 else x.clone())   # replicated-feature path
+        emb_b = ShardedPinSage(params, 2, _Sampler(cg, 77), M, ops=OracleOps()).embed(x[pipe.lo:pipe.hi], T)
+        assert torch.equal(emb, emb_b)                       # all-gathered layer-0 rows == recomputed ones
         codes = pipe.build_index(emb, A)
         nq_local = 8
         d, i = pipe.search(emb[:nq_local], K)
