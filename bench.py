@@ -286,7 +286,7 @@ def main():
 
 def numpy_mode_probe(graph, model, pipe, x_loc, T, W, L, M, dev):
     """The numpy-compatible RNG mode (bit-exact with the reference's np.random stream), with the MT19937
-    stream generated on the device inside the timed region."""
+    stream generated on the device (GF(2) jump-ahead, 2^16-word chunks) inside the timed region."""
     from pinsage_hip import dense, sampling
     from utils.random_walk import RandomWalkSampler
     smp = RandomWalkSampler.from_graph(graph, L, W, rng="numpy")
@@ -306,7 +306,8 @@ def numpy_mode_probe(graph, model, pipe, x_loc, T, W, L, M, dev):
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     return {"embeddings_per_s": M / min(ts), "ms": min(ts) * 1e3,
-            "note": "np.random MT19937 stream generated on device (serial twist) + sampler + pooled forward"}
+            "note": "reference-exact RNG mode: np.random MT19937 stream generated on device (jump-ahead chunks) + "
+                    "sampler + pooled forward; global np.random state handed back"}
 
 
 def cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq):

@@ -1,17 +1,27 @@
 // mt19937.hip -- numpy's legacy global RNG stream, generated on the device.
 //
-// The reference draws one `random_sample()` double from the process-global MT19937 per taken walk
-// step (np.random.choice at utils/random_walk.py:79).  ps_mt19937_random_sample reproduces n such
-// doubles from a given state (key[624], pos) and returns the advanced state, so the host can
-// `np.random.set_state` afterwards and every later consumer of np.random sees the stream the
-// reference would have left behind.
-//   word stream : standard MT19937 twist (3 dependency phases per 624 words, LDS resident) + tempering
+// The reference draws one `random_sample()` double from the process-global MT19937 per taken walk step
+// (np.random.choice at utils/random_walk.py:79).  ps_mt19937_random_sample reproduces n such doubles from a
+// given state (key[624], pos), optionally after skipping `skip` doubles (item shards of a multi-GPU job), and
+// returns the advanced state, so the host can `np.random.set_state` afterwards and every later consumer of
+// np.random sees the stream the reference would have left behind.
+//   word stream : MT19937 recurrence x_{n+624} = x_{n+397} ^ twist(x_n, x_{n+1}), then tempering
 //   double      : genrand_res53: a = w0 >> 5, b = w1 >> 6, (a * 2^26 + b) / 2^53
-// The twist is a serial recurrence (parallelism 227), so the generator is one workgroup; the pair
-// -> double conversion is a separate fully parallel pass done in place.
+// The recurrence is serial (parallelism 227 per 624 words), so the stream is cut into 2^16-word chunks that
+// independent workgroups generate; the 624-word window at the start of every chunk comes from GF(2) jump-ahead:
+// with g(t) = t^(2^m) mod phi(t) (pinsage_hip/mtjump.py), the window 2^m words ahead is the XOR of the windows
+// at the offsets i with g_i = 1 -- one workgroup expands 19937 + 624 words of the sequence into LDS and every
+// thread XORs its output word.  Chunk windows are produced by doubling (1 -> 2 -> 4 ... windows per round).
+// Without polynomials (or for short requests) a single workgroup generates the stream serially.
 #include "ps_common.h"
 
 namespace {
+
+constexpr int MT_N = 624, MT_M = 397;
+constexpr int DEG = 19937;
+constexpr int CHUNK_LOG2 = 16;
+constexpr int64_t CHUNK = (int64_t)1 << CHUNK_LOG2;     // words per chunk
+constexpr int SEQ_WORDS = DEG + MT_N;                   // 20561 words of LDS for one jump
 
 __device__ __forceinline__ uint32_t twist(uint32_t u, uint32_t v) {
     const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
@@ -25,61 +35,243 @@ __device__ __forceinline__ uint32_t temper(uint32_t y) {
     return y;
 }
 
-// raw: 2n tempered words written into `out` (reinterpreted), state/pos advanced.
+// next 624 words from the previous 624 (o -> n), all threads of the block; 3 dependency phases + the last word
+__device__ __forceinline__ void next_block(const uint32_t *o, uint32_t *n, int t) {
+    if (t < 227) n[t] = o[t + MT_M] ^ twist(o[t], o[t + 1]);
+    __syncthreads();
+    if (t < 227) { const int i = 227 + t; n[i] = n[i - 227] ^ twist(o[i], o[i + 1]); }
+    __syncthreads();
+    if (t < 169) { const int i = 454 + t; n[i] = n[i - 227] ^ twist(o[i], o[i + 1]); }
+    __syncthreads();
+    if (t == 0) n[623] = n[396] ^ twist(o[623], n[0]);
+    __syncthreads();
+}
+
+// ---- serial path: one workgroup, raw (tempered) words written in place of the doubles ----------------------
 __global__ __launch_bounds__(256) void mt_words_kernel(const uint32_t *state_in, int pos_in, int64_t nwords,
                                                        uint32_t *raw, uint32_t *state_out, int32_t *pos_out) {
-    __shared__ uint32_t mt[2][624];
+    __shared__ uint32_t mt[2][MT_N];
     const int t = threadIdx.x;
-    for (int i = t; i < 624; i += 256) mt[0][i] = state_in[i];
+    for (int i = t; i < MT_N; i += 256) mt[0][i] = state_in[i];
     __syncthreads();
     int cur = 0, pos = pos_in;
     int64_t done = 0;
     while (done < nwords) {
-        if (pos >= 624) {   // regenerate the whole block: new = mt[cur^1]
-            uint32_t *o = mt[cur], *n = mt[cur ^ 1];
-            if (t < 227) n[t] = o[t + 397] ^ twist(o[t], o[t + 1]);
-            __syncthreads();
-            if (t < 227) { const int i = 227 + t; n[i] = n[i - 227] ^ twist(o[i], o[i + 1]); }
-            __syncthreads();
-            if (t < 169) { const int i = 454 + t; n[i] = n[i - 227] ^ twist(o[i], o[i + 1]); }
-            __syncthreads();
-            if (t == 0) n[623] = n[396] ^ twist(o[623], n[0]);
-            __syncthreads();
+        if (pos >= MT_N) {
+            next_block(mt[cur], mt[cur ^ 1], t);
             cur ^= 1;
             pos = 0;
         }
         const int64_t rem = nwords - done;
-        const int take = (624 - pos) < rem ? (624 - pos) : (int)rem;
+        const int take = (MT_N - pos) < rem ? (MT_N - pos) : (int)rem;
         for (int i = t; i < take; i += 256) raw[done + i] = temper(mt[cur][pos + i]);
         pos += take;
         done += take;
     }
     __syncthreads();
-    for (int i = t; i < 624; i += 256) state_out[i] = mt[cur][i];
+    for (int i = t; i < MT_N; i += 256) state_out[i] = mt[cur][i];
     if (t == 0) pos_out[0] = pos;
 }
 
-__global__ void mt_pairs_to_double_kernel(double *out, int64_t n) {
+__global__ void mt_pairs_to_double_kernel(double *out, int64_t n) {      // serial path: in place
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint2 w = reinterpret_cast<const uint2 *>(out)[i];
         out[i] = ((double)(w.x >> 5) * 67108864.0 + (double)(w.y >> 6)) * (1.0 / 9007199254740992.0);
     }
 }
 
+// ---- parallel path --------------------------------------------------------------------------------------
+// Stream word w = 0 is the next word numpy would output (key[pos], or the first word after a twist when
+// pos == 624).  W1 = the 624 raw words at stream indices 1..624 is the base of all jumps (word 0's low bits are
+// not part of the 19937-bit state when it has never been produced by the recurrence).
+__global__ __launch_bounds__(256) void mt_prepare_kernel(const uint32_t *state_in, int pos_in, uint32_t *w1,
+                                                         uint32_t *word0) {
+    __shared__ uint32_t seq[3 * MT_N];
+    const int t = threadIdx.x;
+    for (int i = t; i < MT_N; i += 256) seq[i] = state_in[i];
+    __syncthreads();
+    next_block(seq, seq + MT_N, t);
+    next_block(seq + MT_N, seq + 2 * MT_N, t);
+    for (int i = t; i < MT_N; i += 256) w1[i] = seq[pos_in + 1 + i];
+    if (t == 0) word0[0] = seq[pos_in];
+}
+
+// dst[b] = window 2^m words after src[b] (poly = coefficients of t^(2^m) mod phi, 624 words, LSB first)
+__global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t *src, const uint32_t *poly, uint32_t *dst) {
+    __shared__ uint32_t seq[SEQ_WORDS + 2 * MT_N];   // 87 KB: the expansion runs in whole 624-word blocks
+    const int t = threadIdx.x;
+    const uint32_t *s = src + (size_t)blockIdx.x * MT_N;
+    if (t < MT_N) seq[t] = s[t];
+    __syncthreads();
+    for (int base = 0; base + MT_N < SEQ_WORDS + MT_N; base += MT_N) next_block(seq + base, seq + base + MT_N, t);
+    uint32_t acc = 0;
+    if (t < MT_N) {
+        for (int w = 0; w < MT_N; ++w) {
+            uint32_t bits = poly[w];               // block-uniform
+            const uint32_t *p = seq + w * 32 + t;
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                acc ^= p[b];
+            }
+        }
+        dst[(size_t)blockIdx.x * MT_N + t] = acc;
+    }
+}
+
+// chunk c (window = states[c]) holds stream words [1 + (c0 + c) * CHUNK, +CHUNK); raw[w - w_lo] for w in [w_lo, w_hi)
+__global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, int64_t c0, int64_t w_lo, int64_t w_hi,
+                                                       uint32_t *raw) {
+    __shared__ uint32_t mt[2][MT_N];
+    const int t = threadIdx.x;
+    const int64_t wbase = 1 + (c0 + blockIdx.x) * CHUNK;
+    for (int i = t; i < MT_N; i += 256) mt[0][i] = states[(size_t)blockIdx.x * MT_N + i];
+    __syncthreads();
+    int cur = 0;
+    for (int64_t off = 0; off < CHUNK; off += MT_N) {
+        const int take = (CHUNK - off) < MT_N ? (int)(CHUNK - off) : MT_N;
+        for (int i = t; i < take; i += 256) {
+            const int64_t w = wbase + off + i;
+            if (w >= w_lo && w < w_hi) raw[w - w_lo] = mt[cur][i];
+        }
+        if (off + MT_N < CHUNK) {
+            next_block(mt[cur], mt[cur ^ 1], t);
+            cur ^= 1;
+        }
+    }
+}
+
+__global__ void mt_raw_to_double_kernel(const uint32_t *raw, int64_t w_lo, int64_t skip, int64_t n, double *out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t w = 2 * (skip + i) - w_lo;
+        const uint32_t a = temper(raw[w]), b = temper(raw[w + 1]);
+        out[i] = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+    }
+}
+
+__global__ void mt_set_pos_kernel(int pos, int32_t *pos_out) { pos_out[0] = pos; }
+
+__global__ void mt_final_state_kernel(const uint32_t *raw, int64_t w_lo, int64_t key_w, int pos, uint32_t *state_out,
+                                      int32_t *pos_out) {
+    for (int i = threadIdx.x; i < MT_N; i += blockDim.x) state_out[i] = raw[key_w - w_lo + i];
+    if (threadIdx.x == 0) pos_out[0] = pos;
+}
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct Plan {
+    int64_t wa, wb;          // needed output words [wa, wb)
+    int64_t key_w;           // stream index of the final key's first word (may be < 0: key unchanged)
+    int pos_out;
+    int64_t w_lo, w_hi;      // raw words kept
+    int64_t c0, c1;          // chunks (relative to W1) covering [max(w_lo, 1), w_hi)
+};
+
+Plan make_plan(int pos_in, int64_t skip, int64_t n) {
+    Plan p;
+    p.wa = 2 * skip;
+    p.wb = 2 * (skip + n);
+    const int64_t consumed = pos_in + p.wb;             // words from the start of the current block
+    int64_t q = consumed / MT_N, r = consumed % MT_N;
+    if (r == 0 && p.wb > 0) { q -= 1; r = MT_N; }
+    p.pos_out = (int)r;
+    p.key_w = q * MT_N - pos_in;
+    p.w_lo = p.wa;
+    if (p.key_w >= 0 && p.key_w < p.w_lo) p.w_lo = p.key_w;
+    p.w_hi = p.wb;
+    if (p.key_w >= 0 && p.key_w + MT_N > p.w_hi) p.w_hi = p.key_w + MT_N;
+    const int64_t first = p.w_lo < 1 ? 1 : p.w_lo;
+    p.c0 = (first - 1) / CHUNK;
+    p.c1 = (p.w_hi - 2) / CHUNK;
+    if (p.c1 < p.c0) p.c1 = p.c0;
+    return p;
+}
+
 }  // namespace
 
-extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t n, double *out,
-                                        uint32_t *state_out, int32_t *pos_out, ps_stream_t stream) {
-    if (!state_in || !state_out || !pos_out || n < 0 || pos_in < 0 || pos_in > 624) return PS_EINVAL;
+extern "C" size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n) {
+    if (n < 0 || skip < 0) return 0;
+    const Plan p = make_plan(MT_N, skip, n);            // pos only shifts the plan by < 624 words
+    const int64_t K = p.c1 - p.c0 + 2;
+    return align256((size_t)(2 * K + 4) * MT_N * 4) + align256((size_t)(p.w_hi - p.w_lo + 2 * MT_N + CHUNK) * 4) + 4096;
+}
+
+extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,
+                                        uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys,
+                                        int jump_levels, void *workspace, size_t workspace_bytes, ps_stream_t stream) {
+    if (!state_in || !state_out || !pos_out || n < 0 || skip < 0 || pos_in < 0 || pos_in > MT_N) return PS_EINVAL;
     if (n > 0 && !out) return PS_EINVAL;
     hipStream_t st = ps_stream(stream);
-    hipLaunchKernelGGL(mt_words_kernel, dim3(1), dim3(256), 0, st, state_in, pos_in, 2 * n,
-                       reinterpret_cast<uint32_t *>(out), state_out, pos_out);
+    if (n == 0 && skip == 0) {                          // nothing consumed: state unchanged
+        if (hipMemcpyAsync(state_out, state_in, MT_N * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
+        hipLaunchKernelGGL(mt_set_pos_kernel, dim3(1), dim3(1), 0, st, pos_in, pos_out);
+        PS_CHECK_LAUNCH();
+        return PS_OK;
+    }
+    const bool parallel = jump_polys != nullptr && workspace != nullptr && (skip > 0 || n >= (1 << 17));
+    if (!parallel) {
+        if (skip != 0) return PS_EUNSUPPORTED;          // skipping needs the jump polynomials
+        hipLaunchKernelGGL(mt_words_kernel, dim3(1), dim3(256), 0, st, state_in, pos_in, 2 * n,
+                           reinterpret_cast<uint32_t *>(out), state_out, pos_out);
+        PS_CHECK_LAUNCH();
+        if (n > 0) {
+            int64_t grid = ps_cdiv(n, 256);
+            if (grid > 8192) grid = 8192;
+            hipLaunchKernelGGL(mt_pairs_to_double_kernel, dim3((unsigned)grid), dim3(256), 0, st, out, n);
+            PS_CHECK_LAUNCH();
+        }
+        return PS_OK;
+    }
+    const Plan p = make_plan(pos_in, skip, n);
+    const int64_t K = p.c1 - p.c0 + 1;
+    if (workspace_bytes < ps_mt19937_workspace_bytes(skip, n)) return PS_EWORKSPACE;
+    if ((p.c1 >> (jump_levels - CHUNK_LOG2)) != 0) return PS_EUNSUPPORTED;   // offset beyond the polynomial table
+    char *base = reinterpret_cast<char *>(align256(reinterpret_cast<size_t>(workspace)));
+    uint32_t *states = reinterpret_cast<uint32_t *>(base);                   // [K] chunk windows
+    uint32_t *tmpA = states + (size_t)(K + 1) * MT_N;                        // ping-pong for the base jump
+    uint32_t *tmpB = tmpA + MT_N;
+    uint32_t *word0 = tmpB + MT_N;
+    uint32_t *raw = reinterpret_cast<uint32_t *>(base + align256((size_t)(2 * K + 4) * MT_N * 4));
+    const size_t jump_lds = 0;
+    // 1. W1 and word 0
+    hipLaunchKernelGGL(mt_prepare_kernel, dim3(1), dim3(256), 0, st, state_in, pos_in, tmpA, word0);
     PS_CHECK_LAUNCH();
+    // 2. base jump to chunk c0: offset c0 * CHUNK words = set bits of c0 at levels CHUNK_LOG2 + b
+    uint32_t *cur = tmpA, *nxt = tmpB;
+    for (int b = 0; (p.c0 >> b) != 0; ++b) {
+        if (!((p.c0 >> b) & 1)) continue;
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(1), dim3(640), jump_lds, st, cur, jump_polys + (size_t)(CHUNK_LOG2 + b) * MT_N, nxt);
+        PS_CHECK_LAUNCH();
+        uint32_t *t = cur; cur = nxt; nxt = t;
+    }
+    if (hipMemcpyAsync(states, cur, MT_N * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
+    // 3. doubling: states[2^m + r] = jump_{CHUNK * 2^m}(states[r])
+    for (int m = 0; ((int64_t)1 << m) < K; ++m) {
+        const int64_t have = (int64_t)1 << m;
+        const int64_t make = (K - have) < have ? (K - have) : have;
+        hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)make), dim3(640), jump_lds, st, states,
+                           jump_polys + (size_t)(CHUNK_LOG2 + m) * MT_N, states + (size_t)have * MT_N);
+        PS_CHECK_LAUNCH();
+    }
+    // 4. chunks -> raw words; word 0 separately
+    hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)K), dim3(256), 0, st, states, p.c0, p.w_lo, p.w_hi, raw);
+    PS_CHECK_LAUNCH();
+    if (p.w_lo == 0)
+        if (hipMemcpyAsync(raw, word0, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
+    // 5. doubles
     if (n > 0) {
         int64_t grid = ps_cdiv(n, 256);
         if (grid > 8192) grid = 8192;
-        hipLaunchKernelGGL(mt_pairs_to_double_kernel, dim3((unsigned)grid), dim3(256), 0, st, out, n);
+        hipLaunchKernelGGL(mt_raw_to_double_kernel, dim3((unsigned)grid), dim3(256), 0, st, raw, p.w_lo, skip, n, out);
+        PS_CHECK_LAUNCH();
+    }
+    // 6. the state numpy would be left in
+    if (p.key_w >= 0) {
+        hipLaunchKernelGGL(mt_final_state_kernel, dim3(1), dim3(256), 0, st, raw, p.w_lo, p.key_w, p.pos_out, state_out, pos_out);
+        PS_CHECK_LAUNCH();
+    } else {
+        if (hipMemcpyAsync(state_out, state_in, MT_N * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
+        hipLaunchKernelGGL(mt_set_pos_kernel, dim3(1), dim3(1), 0, st, p.pos_out, pos_out);
         PS_CHECK_LAUNCH();
     }
     return PS_OK;

@@ -106,6 +106,9 @@ def _nodes_tensor(nodes, device, num_nodes):
 def draw_numpy_uniforms(n, device):
     """n doubles of the process-global legacy numpy stream, exactly what n sequential
     `np.random.choice(..., p=...)` calls consume (utils/random_walk.py:79), staged to HBM."""
+    if n >= (1 << 17):
+        from . import dense                    # same stream, generated on the device (jump-ahead chunks)
+        return dense.mt19937_random_sample(int(n), device)
     u = np.random.random_sample(int(n))
     t = torch.from_numpy(u)
     if n:

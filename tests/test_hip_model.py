@@ -217,67 +217,26 @@ def test_exact_topk_golden_and_oracle(golden):
 
 
 def test_device_mt19937_matches_numpy():
+    """Serial and jump-ahead (parallel chunk) generation of numpy's global stream, incl. odd word positions,
+    skipped prefixes (multi-GPU shards) and the advanced global state."""
     from pinsage_hip import dense
-    for seed, burn, n in ((42, 0, 5000), (0, 3, 1249), (123, 311, 100000), (7, 1, 1)):
+    cases = [(42, 0, 5000, 0), (0, 3, 1249, 0), (123, 311, 300000, 0), (7, 1, 1, 0), (5, 10, 200000, 123457),
+             (11, 77, 4096, 5000000), (13, 624, 131072, 0), (17, 5, 1 << 20, 1 << 22), (9, 0, 11809400, 0)]
+    for seed, burn, n, skip in cases:
         np.random.seed(seed)
         np.random.random_sample(burn)
         if burn % 2:
             np.random.randint(0, 10)                               # odd word position
         st = np.random.get_state()
+        np.random.random_sample(skip)
         ref = np.random.random_sample(n)
         tail = np.random.random_sample()
         np.random.set_state(st)
-        out = dense.mt19937_random_sample(n, "cuda").cpu().numpy()
-        assert np.array_equal(out, ref)
-        assert np.random.random_sample() == tail                   # global state advanced identically
-
-
-def test_l2_topk_and_ivf_masked_search():
-    """ps_l2_topk: exact squared-L2 k-NN (IndexFlatL2) and the probed-lists restriction (IndexIVFFlat) vs a
-    numpy restatement: ids identical (by (distance, id)), distances to 1e-5."""
-    from pinsage_hip import dense
-    rs = np.random.RandomState(5)
-    N, D, nq, k, nlist = 4000, 48, 300, 10, 37
-    X = rs.standard_normal((N, D)).astype(np.float32)
-    Q = X[:nq] + 0.05 * rs.standard_normal((nq, D)).astype(np.float32)
-    assign = rs.randint(0, nlist, size=N).astype(np.int32)
-    d2 = ((Q[:, None, :].astype(np.float64) - X[None, :, :].astype(np.float64)) ** 2).sum(-1)
-    order = np.argsort(d2, axis=1, kind="stable")[:, :k]
-    dist, ids = dense.l2_topk(torch.from_numpy(X).cuda(), torch.from_numpy(Q).cuda(), k)
-    assert np.array_equal(ids.cpu().numpy(), order)
-    np.testing.assert_allclose(dist.cpu().numpy(), np.take_along_axis(d2, order, 1), rtol=1e-4, atol=1e-4)
-    # probe 5 random lists per query
-    probe_lists = np.stack([rs.permutation(nlist)[:5] for _ in range(nq)])
-    words = (nlist + 31) // 32
-    bits = np.zeros((nq, words), dtype=np.uint32)
-    for r in range(nq):
-        for l in probe_lists[r]:
-            bits[r, l >> 5] |= np.uint32(1) << np.uint32(l & 31)
-    vis = (probe_lists[:, :, None] == assign[None, None, :]).any(axis=1)
-    dm = np.where(vis, d2, np.inf)
-    order_m = np.argsort(dm, axis=1, kind="stable")[:, :k]
-    dist, ids = dense.l2_topk(torch.from_numpy(X).cuda(), torch.from_numpy(Q).cuda(), k,
-                              assign=torch.from_numpy(assign).cuda(), probe=torch.from_numpy(bits.view(np.int32)).cuda())
-    assert np.array_equal(ids.cpu().numpy(), order_m)
-
-
-def test_weakand_index_and_benchmark_harness(capsys):
-    from utils.nearest_neighbors import WeakANDIndex, benchmark_search_methods
-    rs = np.random.RandomState(2)
-    centers = rs.standard_normal((40, 32)).astype(np.float32) * 3
-    emb = (centers[rs.randint(0, 40, size=6000)] + 0.3 * rs.standard_normal((6000, 32))).astype(np.float32)
-    idx = WeakANDIndex(32, num_partitions=50)
-    idx.build(emb)
-    assert idx.index.ntotal == 6000 and idx.index.is_trained and idx.quantizer.ntotal == 50
-    d, i = idx.search(emb[:64], k=10)
-    assert d.shape == (64, 10) and i.dtype == np.int64 and d.dtype == np.float32
-    assert idx.index.nprobe == 20
-    assert np.array_equal(i[:, 0], np.arange(64)) and np.all(np.abs(d[:, 0]) < 1e-3)     # self is nearest
-    assert np.all(np.diff(d, axis=1) >= -1e-6)
-    res = benchmark_search_methods(torch.from_numpy(emb), emb[:128], k=10)
-    assert set(res) == {"exact", "lsh", "ivf"}
-    for m in res.values():
-        assert set(m) >= {"distances", "indices", "search_time", "index_size", "method"} and m["index_size"] == 6000
-    assert res["ivf"]["recall"] > 0.9 and 0.0 < res["lsh"]["recall"] <= 1.0
-    out = capsys.readouterr().out
-    assert "Built Weak AND index with 6000 embeddings" in out and "recall@10" in out
+        out = dense.mt19937_random_sample(n, "cuda", skip=skip).cpu().numpy()
+        assert np.array_equal(out, ref), (seed, burn, n, skip)
+        assert np.random.random_sample() == tail, (seed, burn, n, skip)     # global state advanced identically
+    # the serial kernel gives the same stream
+    np.random.seed(3)
+    a = dense.mt19937_random_sample(200000, "cuda", advance=False, parallel=False)
+    b = dense.mt19937_random_sample(200000, "cuda", advance=False, parallel=True)
+    assert torch.equal(a, b)

@@ -1,0 +1,41 @@
+"""MT19937 jump-ahead polynomials (host GF(2) arithmetic) against numpy's own generator.  CPU only."""
+import numpy as np
+
+
+def _raw_sequence(key, n):
+    x = [int(v) for v in key]
+    while len(x) < n:
+        k = len(x) - 624
+        y = (x[k] & 0x80000000) | (x[k + 1] & 0x7FFFFFFF)
+        x.append(x[k + 397] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0))
+    return np.array(x, dtype=np.uint32)
+
+
+def test_characteristic_polynomial_and_jumps():
+    from pinsage_hip import mtjump
+    phi = mtjump.characteristic_polynomial()
+    assert phi.bit_length() - 1 == 19937 and bin(phi).count("1") == 135      # Matsumoto & Nishimura: 135 terms
+    P = mtjump.jump_polynomials()
+    assert P.shape == (mtjump.JUMP_LEVELS, 624) and P.dtype == np.uint32
+    assert P[0, 0] == 2 and P[0, 1:].sum() == 0                               # t^1
+    key = np.random.RandomState(2024).get_state()[1]
+    seq = _raw_sequence(key, 624 + (1 << 17) + 1400)
+    for level in (3, 12, 15, 16, 17):
+        w = mtjump.apply_jump_reference(seq[700:700 + 624], level)
+        assert np.array_equal(w, seq[700 + (1 << level):700 + (1 << level) + 624]), level
+
+
+def test_raw_sequence_is_numpys_stream():
+    """The recurrence used by the jump code is numpy's generator: tempered raw words == random_sample bits."""
+    rs = np.random.RandomState(99)
+    key = rs.get_state()[1]
+    seq = _raw_sequence(key, 624 + 2000)[624:]                                # first twisted block onwards
+    y = seq.astype(np.uint64)
+    y ^= y >> np.uint64(11)
+    y ^= (y << np.uint64(7)) & np.uint64(0x9D2C5680)
+    y ^= (y << np.uint64(15)) & np.uint64(0xEFC60000)
+    y ^= y >> np.uint64(18)
+    y &= np.uint64(0xFFFFFFFF)
+    a, b = y[0:2000:2] >> np.uint64(5), y[1:2000:2] >> np.uint64(6)
+    ref = rs.random_sample(1000)
+    assert np.array_equal((a.astype(np.float64) * 67108864.0 + b.astype(np.float64)) / 9007199254740992.0, ref)
