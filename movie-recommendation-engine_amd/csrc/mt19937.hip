@@ -99,23 +99,32 @@ __global__ __launch_bounds__(256) void mt_prepare_kernel(const uint32_t *state_i
 // dst[b] = window 2^m words after src[b] (poly = coefficients of t^(2^m) mod phi, 624 words, LSB first)
 __global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t *src, const uint32_t *poly, uint32_t *dst) {
     __shared__ uint32_t seq[SEQ_WORDS + 2 * MT_N];   // 87 KB: the expansion runs in whole 624-word blocks
+    __shared__ uint32_t pl[MT_N + 1];                // the polynomial (read by every thread: keep it out of HBM)
     const int t = threadIdx.x;
     const uint32_t *s = src + (size_t)blockIdx.x * MT_N;
-    if (t < MT_N) seq[t] = s[t];
+    if (t < MT_N) { seq[t] = s[t]; pl[t] = poly[t]; }
+    if (t == 0) pl[MT_N] = 0u;
     __syncthreads();
     for (int base = 0; base + MT_N < SEQ_WORDS + MT_N; base += MT_N) next_block(seq + base, seq + base + MT_N, t);
-    uint32_t acc = 0;
     if (t < MT_N) {
+        uint32_t acc0 = 0, acc1 = 0;
+        uint32_t bits = pl[0];
         for (int w = 0; w < MT_N; ++w) {
-            uint32_t bits = poly[w];               // block-uniform
+            const uint32_t nextbits = pl[w + 1];       // fetched while this word's set bits are applied
             const uint32_t *p = seq + w * 32 + t;
-            while (bits) {
-                const int b = __builtin_ctz(bits);
+            while (bits) {                             // two set bits per trip: two independent LDS reads
+                const int b0 = __builtin_ctz(bits);
                 bits &= bits - 1u;
-                acc ^= p[b];
+                acc0 ^= p[b0];
+                if (bits) {
+                    const int b1 = __builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    acc1 ^= p[b1];
+                }
             }
+            bits = nextbits;
         }
-        dst[(size_t)blockIdx.x * MT_N + t] = acc;
+        dst[(size_t)blockIdx.x * MT_N + t] = acc0 ^ acc1;
     }
 }
 
