@@ -240,3 +240,58 @@ def test_device_mt19937_matches_numpy():
     a = dense.mt19937_random_sample(200000, "cuda", advance=False, parallel=False)
     b = dense.mt19937_random_sample(200000, "cuda", advance=False, parallel=True)
     assert torch.equal(a, b)
+
+
+def test_inference_style_flow_unchanged_call_sites():
+    """The call pattern of the reference's inference driver, written against the drop-in classes: per 1024-item
+    batch, `num_layers` x sampler.batch_sample_neighbors(batch_indices, T), the POSITIONAL model(x, neighbors,
+    weights) call (inference.py:43-52), then LSHIndex(dim, bits, tables).build / .search(q[1, D], k) and dropping
+    the query itself (inference.py:73-76, 120-127).  Checked against the oracle on the same numpy stream."""
+    from oracle import c_oracle as co
+    from pinsage_hip import synth
+    from utils.random_walk import RandomWalkSampler
+    from utils.nearest_neighbors import LSHIndex
+    from model.pinsage import PinSage
+    dev = torch.device("cuda")
+    ei, ew = synth.bipartite_ratings(500, 1500, 40000, seed=3)
+    M = 1500
+    sampler = RandomWalkSampler(ei, ew, walk_length=2, num_walks=100)
+    torch.manual_seed(1)
+    model = PinSage(32, 64, 32, num_layers=2).to(dev).eval()
+    feats = torch.randn(M, 32)
+    np.random.seed(42)
+    embs = []
+    with torch.no_grad():
+        for i in range(0, M, 1024):
+            batch_indices = torch.arange(i, min(i + 1024, M))
+            all_neighbors, all_weights = [], []
+            for _ in range(model.num_layers):
+                nb, wt = sampler.batch_sample_neighbors(batch_indices, 10)
+                all_neighbors.append(nb)
+                all_weights.append(wt)
+            # batch-local features with global neighbour ids, exactly what the driver passes
+            out = model(feats[i:i + 1024].to(dev), all_neighbors, all_weights)
+            embs.append(out.cpu())
+    emb = torch.cat(embs)
+    assert emb.shape == (M, 32)
+    # oracle with the same stream and the same batch-local semantics (ids <= len(batch)-1 kept, pinsage.py:124)
+    cg = co.Graph(ei.numpy(), ew.numpy())
+    rs = np.random.RandomState(42)
+    params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    refs = []
+    for i in range(0, M, 1024):
+        nodes = np.arange(i, min(i + 1024, M))
+        layers = []
+        for _ in range(2):
+            uoff, n = cg.uniform_offsets(nodes, 100, 2)
+            ids, counts, nv, _, _, _ = co.walk_sample(cg, nodes, 10, 2, 100, uniforms=rs.random_sample(n))
+            layers.append((ids, counts, nv))
+        refs.append(co.pinsage_forward(params, feats[i:i + 1024].numpy(), layers))
+    np.testing.assert_allclose(emb.numpy(), np.concatenate(refs), rtol=RTOL, atol=ATOL)
+    assert np.random.random_sample() == rs.random_sample()
+    index = LSHIndex(32, 64, 16)
+    index.build(emb)
+    q = 17
+    _, indices = index.search(emb[q].unsqueeze(0).numpy(), k=11)
+    rec = [idx for idx in indices[0] if idx != q][:10]
+    assert len(rec) == 10 and q not in rec and indices[0][0] == q
