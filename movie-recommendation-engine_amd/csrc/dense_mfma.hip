@@ -84,10 +84,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         auto fetch = [&](int k0) {
 #pragma unroll
             for (int q = 0; q < A_ITEMS; ++q) {
-                const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
+                // FAST: no guards -- when the tile has fewer items than threads the surplus threads duplicate an
+                // item (identical loads, identical LDS writes)
+                const int it = FAST ? (tid + 256 * q) % (BM * GRP) : tid + 256 * q, row = it / GRP, grp = it % GRP;
                 const int64_t m = m0 + row;
                 if (FAST) {
-                    static_assert(!FAST || (BM * GRP) % 256 == 0, "FAST needs whole items per thread");
                     {
                         const float *src = X + (m < g.M ? m : g.M - 1) * K + k0 + grp * 8;
                         const float4 a = *reinterpret_cast<const float4 *>(src);
@@ -99,10 +100,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             }
 #pragma unroll
             for (int q = 0; q < B_ITEMS; ++q) {
-                const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
+                const int it = FAST ? (tid + 256 * q) % (BN * GRP) : tid + 256 * q, row = it / GRP, grp = it % GRP;
                 const int n = n0 + row;
                 if (FAST) {
-                    static_assert(!FAST || (BN * GRP) % 256 == 0, "FAST needs whole items per thread");
                     {
                         const float *src = Wp + (int64_t)(n < g.N ? n : g.N - 1) * ldw + k0 + grp * 8;
                         const float4 a = *reinterpret_cast<const float4 *>(src);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         auto stash = [&]() {
 #pragma unroll
             for (int q = 0; q < A_ITEMS; ++q) {
-                const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
+                const int it = FAST ? (tid + 256 * q) % (BM * GRP) : tid + 256 * q, row = it / GRP, grp = it % GRP;
                 if (!FAST && it >= BM * GRP) continue;
                 float *d = sA + row * LDS_STRIDE + grp * 8;
                 *reinterpret_cast<float4 *>(d) = make_float4(ra[q][0], ra[q][2], ra[q][4], ra[q][6]);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             }
 #pragma unroll
             for (int q = 0; q < B_ITEMS; ++q) {
-                const int it = tid + 256 * q, row = it / GRP, grp = it % GRP;
+                const int it = FAST ? (tid + 256 * q) % (BN * GRP) : tid + 256 * q, row = it / GRP, grp = it % GRP;
                 if (!FAST && it >= BN * GRP) continue;
                 float *d = sB + row * LDS_STRIDE + grp * 8;
                 *reinterpret_cast<float4 *>(d) = make_float4(rb[q][0], rb[q][2], rb[q][4], rb[q][6]);
@@ -277,6 +277,7 @@ int launch_gemm_v(const GemmArgs &g, hipStream_t st) {
         dim3 grid((unsigned)ps_cdiv(g.M, 64), 1);
         hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
     } else {
+        // 64 x 256 tiles; 32-row tiles (3 blocks/CU) measured 8 % slower, BK = 16 6 % slower
         dim3 grid((unsigned)ps_cdiv(g.M, 64), (unsigned)ps_cdiv(g.N, 256));
         hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 2, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
     }

@@ -295,3 +295,53 @@ def test_inference_style_flow_unchanged_call_sites():
     _, indices = index.search(emb[q].unsqueeze(0).numpy(), k=11)
     rec = [idx for idx in indices[0] if idx != q][:10]
     assert len(rec) == 10 and q not in rec and indices[0][0] == q
+
+
+def test_config0_ml100k_shape_end_to_end_vs_oracle():
+    """BASELINE configs[0]: ML-100K-shaped graph, d=64, 1 GCN layer, T=5 neighbours, exact brute-force search
+    (K = 11): the whole path against the oracle on the same numpy stream."""
+    from oracle import c_oracle as co
+    from pinsage_hip import synth
+    from utils.random_walk import RandomWalkSampler
+    from utils.nearest_neighbors import ExactIndex
+    from model.pinsage import PinSage
+    dev = torch.device("cuda")
+    ei, ew = synth.bipartite_ratings(**synth.ML100K, seed=20240601)
+    M = synth.ML100K["num_items"]
+    sampler = RandomWalkSampler(ei, ew, walk_length=2, num_walks=100)
+    torch.manual_seed(2)
+    model = PinSage(128, 256, 64, num_layers=1).to(dev).eval()
+    torch.manual_seed(1)
+    x = torch.randn(M, 128)
+    np.random.seed(42)
+    with torch.no_grad():
+        emb = model.get_embeddings(x.to(dev), sampler, num_neighbors=5)
+    cg = co.Graph(ei.numpy(), ew.numpy())
+    rs = np.random.RandomState(42)
+    uoff, n = cg.uniform_offsets(np.arange(M), 100, 2)
+    ids, counts, nv, _, _, _ = co.walk_sample(cg, np.arange(M), 5, 2, 100, uniforms=rs.random_sample(n))
+    params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ref = co.pinsage_forward(params, x.numpy(), [(ids, counts, nv)], threads=8)
+    np.testing.assert_allclose(emb.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    ex = ExactIndex(64)
+    ex.build(emb)
+    q = np.arange(0, M, 13)
+    vals, got = ex.search_indices(q, 11)
+    rv, ri = co.dot_topk(emb.cpu().numpy(), q, 11, threads=8)
+    np.testing.assert_allclose(vals.cpu().numpy(), rv, rtol=1e-6, atol=1e-7)
+    agree = (got.cpu().numpy() == ri).mean()
+    assert agree == 1.0, agree
+
+
+def test_lsh_num_bits_not_multiple_of_32():
+    from oracle import c_oracle as co
+    from utils.nearest_neighbors import LSHIndex, lsh_rotation_matrix
+    rs = np.random.RandomState(8)
+    emb = rs.standard_normal((700, 40)).astype(np.float32)
+    for nbits in (24, 72, 200):
+        idx = LSHIndex(40, nbits, 16)
+        idx.build(emb)
+        d, i = idx.search(emb[:50], 9)
+        codes = co.lsh_encode(emb, lsh_rotation_matrix(40, nbits))           # nbits real bits per code
+        rd, ri = co.hamming_topk(codes[:50], codes, 9)
+        assert np.array_equal(i, ri) and np.array_equal(d, rd)
