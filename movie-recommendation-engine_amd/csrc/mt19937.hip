@@ -10,8 +10,9 @@
 // The recurrence is serial (parallelism 227 per 624 words), so the stream is cut into 2^16-word chunks that
 // independent workgroups generate; the 624-word window at the start of every chunk comes from GF(2) jump-ahead:
 // with g(t) = t^(2^m) mod phi(t) (pinsage_hip/mtjump.py), the window 2^m words ahead is the XOR of the windows
-// at the offsets i with g_i = 1 -- one workgroup expands 19937 + 624 words of the sequence into LDS and every
-// thread XORs its output word.  Chunk windows are produced by doubling (1 -> 2 -> 4 ... windows per round).
+// at the offsets i with g_i = 1 -- one workgroup expands 34 blocks of the sequence to global memory, then 8
+// workgroups each XOR the windows selected by 1/8 of the polynomial (the 8 partial windows are XORed by whoever
+// reads the window next).  Chunk windows are produced by doubling (1 -> 2 -> 4 ... windows per round).
 // Without polynomials (or for short requests) a single workgroup generates the stream serially.
 #include "ps_common.h"
 
@@ -21,7 +22,6 @@ constexpr int MT_N = 624, MT_M = 397;
 constexpr int DEG = 19937;
 constexpr int CHUNK_LOG2 = 16;
 constexpr int64_t CHUNK = (int64_t)1 << CHUNK_LOG2;     // words per chunk
-constexpr int SEQ_WORDS = DEG + MT_N;                   // 20561 words of LDS for one jump
 
 __device__ __forceinline__ uint32_t twist(uint32_t u, uint32_t v) {
     const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
@@ -96,23 +96,57 @@ __global__ __launch_bounds__(256) void mt_prepare_kernel(const uint32_t *state_i
     if (t == 0) word0[0] = seq[pos_in];
 }
 
-// dst[b] = window 2^m words after src[b] (poly = coefficients of t^(2^m) mod phi, 624 words, LSB first)
-__global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t *src, const uint32_t *poly, uint32_t *dst) {
-    __shared__ uint32_t seq[SEQ_WORDS + 2 * MT_N];   // 87 KB: the expansion runs in whole 624-word blocks
-    __shared__ uint32_t pl[MT_N + 1];                // the polynomial (read by every thread: keep it out of HBM)
+// A window is stored as JP partial vectors whose XOR is the 624-word window (a plain window = itself + zeros).
+constexpr int JP = 8;                                    // workgroups per jump
+constexpr int PW = MT_N / JP;                            // polynomial words per part (78 -> 2496 bits)
+constexpr int SEQ_PAD = 34 * MT_N;                       // expanded sequence per source, whole blocks
+static_assert(SEQ_PAD >= DEG + MT_N && JP * PW == MT_N, "jump geometry");
+
+__device__ __forceinline__ uint32_t load_window_word(const uint32_t *parts, int t) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int p = 0; p < JP; ++p) v ^= parts[p * MT_N + t];
+    return v;
+}
+
+// seq[b] = the 34 * 624 words that start with window b (sequential expansion, one workgroup per source)
+__global__ __launch_bounds__(256) void mt_expand_kernel(const uint32_t *src_parts, uint32_t *seq) {
+    __shared__ uint32_t mt[2][MT_N];
     const int t = threadIdx.x;
-    const uint32_t *s = src + (size_t)blockIdx.x * MT_N;
-    if (t < MT_N) { seq[t] = s[t]; pl[t] = poly[t]; }
-    if (t == 0) pl[MT_N] = 0u;
+    uint32_t *out = seq + (size_t)blockIdx.x * SEQ_PAD;
+    for (int i = t; i < MT_N; i += 256) {
+        const uint32_t v = load_window_word(src_parts + (size_t)blockIdx.x * JP * MT_N, i);
+        mt[0][i] = v;
+        out[i] = v;
+    }
     __syncthreads();
-    for (int base = 0; base + MT_N < SEQ_WORDS + MT_N; base += MT_N) next_block(seq + base, seq + base + MT_N, t);
+    int cur = 0;
+    for (int blk = 1; blk < 34; ++blk) {
+        next_block(mt[cur], mt[cur ^ 1], t);
+        cur ^= 1;
+        for (int i = t; i < MT_N; i += 256) out[blk * MT_N + i] = mt[cur][i];
+    }
+}
+
+// dst_parts[b][p] = XOR over the set bits i of poly words [p*PW, (p+1)*PW) of seq[b][i .. i+624): part p of the
+// window 2^m words after source b (poly = coefficients of t^(2^m) mod phi, 624 words, LSB first)
+__global__ __launch_bounds__(640) void mt_combine_kernel(const uint32_t *seq, const uint32_t *poly, uint32_t *dst_parts) {
+    __shared__ uint32_t sq[PW * 32 + MT_N + 8];
+    __shared__ uint32_t pl[PW + 1];
+    const int t = threadIdx.x;
+    const int b = blockIdx.x / JP, part = blockIdx.x % JP;
+    const uint32_t *s = seq + (size_t)b * SEQ_PAD + part * PW * 32;
+    for (int i = t; i < PW * 32 + MT_N; i += 640) sq[i] = s[i];
+    if (t < PW) pl[t] = poly[part * PW + t];
+    if (t == 0) pl[PW] = 0u;
+    __syncthreads();
     if (t < MT_N) {
         uint32_t acc0 = 0, acc1 = 0;
         uint32_t bits = pl[0];
-        for (int w = 0; w < MT_N; ++w) {
-            const uint32_t nextbits = pl[w + 1];       // fetched while this word's set bits are applied
-            const uint32_t *p = seq + w * 32 + t;
-            while (bits) {                             // two set bits per trip: two independent LDS reads
+        for (int w = 0; w < PW; ++w) {
+            const uint32_t nextbits = pl[w + 1];
+            const uint32_t *p = sq + w * 32 + t;
+            while (bits) {
                 const int b0 = __builtin_ctz(bits);
                 bits &= bits - 1u;
                 acc0 ^= p[b0];
@@ -124,7 +158,7 @@ __global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t *src, const
             }
             bits = nextbits;
         }
-        dst[(size_t)blockIdx.x * MT_N + t] = acc0 ^ acc1;
+        dst_parts[((size_t)b * JP + part) * MT_N + t] = acc0 ^ acc1;
     }
 }
 
@@ -134,7 +168,7 @@ __global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, i
     __shared__ uint32_t mt[2][MT_N];
     const int t = threadIdx.x;
     const int64_t wbase = 1 + (c0 + blockIdx.x) * CHUNK;
-    for (int i = t; i < MT_N; i += 256) mt[0][i] = states[(size_t)blockIdx.x * MT_N + i];
+    for (int i = t; i < MT_N; i += 256) mt[0][i] = load_window_word(states + (size_t)blockIdx.x * JP * MT_N, i);
     __syncthreads();
     int cur = 0;
     for (int64_t off = 0; off < CHUNK; off += MT_N) {
@@ -202,7 +236,9 @@ extern "C" size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n) {
     if (n < 0 || skip < 0) return 0;
     const Plan p = make_plan(MT_N, skip, n);            // pos only shifts the plan by < 624 words
     const int64_t K = p.c1 - p.c0 + 2;
-    return align256((size_t)(2 * K + 4) * MT_N * 4) + align256((size_t)(p.w_hi - p.w_lo + 2 * MT_N + CHUNK) * 4) + 4096;
+    const size_t states = align256((size_t)(K + 4) * JP * MT_N * 4);
+    const size_t seqs = align256((size_t)(K / 2 + 2) * SEQ_PAD * 4);
+    return states + seqs + align256((size_t)(p.w_hi - p.w_lo + 2 * MT_N + CHUNK) * 4) + 4096;
 }
 
 extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,
@@ -236,30 +272,36 @@ extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, in
     if (workspace_bytes < ps_mt19937_workspace_bytes(skip, n)) return PS_EWORKSPACE;
     if ((p.c1 >> (jump_levels - CHUNK_LOG2)) != 0) return PS_EUNSUPPORTED;   // offset beyond the polynomial table
     char *base = reinterpret_cast<char *>(align256(reinterpret_cast<size_t>(workspace)));
-    uint32_t *states = reinterpret_cast<uint32_t *>(base);                   // [K] chunk windows
-    uint32_t *tmpA = states + (size_t)(K + 1) * MT_N;                        // ping-pong for the base jump
-    uint32_t *tmpB = tmpA + MT_N;
-    uint32_t *word0 = tmpB + MT_N;
-    uint32_t *raw = reinterpret_cast<uint32_t *>(base + align256((size_t)(2 * K + 4) * MT_N * 4));
-    const size_t jump_lds = 0;
-    // 1. W1 and word 0
+    const size_t WSZ = (size_t)JP * MT_N;                                    // words per stored window
+    uint32_t *states = reinterpret_cast<uint32_t *>(base);                   // [K] chunk windows (JP parts each)
+    uint32_t *tmpA = states + (size_t)(K + 1) * WSZ;                         // ping-pong for the base jump
+    uint32_t *tmpB = tmpA + WSZ;
+    uint32_t *word0 = tmpB + WSZ;
+    uint32_t *seqs = reinterpret_cast<uint32_t *>(base + align256((size_t)(K + 4) * JP * MT_N * 4));
+    uint32_t *raw = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(seqs) + align256((size_t)(K / 2 + 2) * SEQ_PAD * 4));
+    // 1. W1 (part 0 of tmpA, the other parts zero) and word 0
+    if (hipMemsetAsync(tmpA, 0, WSZ * 4, st) != hipSuccess) return PS_ELAUNCH;
     hipLaunchKernelGGL(mt_prepare_kernel, dim3(1), dim3(256), 0, st, state_in, pos_in, tmpA, word0);
     PS_CHECK_LAUNCH();
     // 2. base jump to chunk c0: offset c0 * CHUNK words = set bits of c0 at levels CHUNK_LOG2 + b
     uint32_t *cur = tmpA, *nxt = tmpB;
     for (int b = 0; (p.c0 >> b) != 0; ++b) {
         if (!((p.c0 >> b) & 1)) continue;
-        hipLaunchKernelGGL(mt_jump_kernel, dim3(1), dim3(640), jump_lds, st, cur, jump_polys + (size_t)(CHUNK_LOG2 + b) * MT_N, nxt);
+        hipLaunchKernelGGL(mt_expand_kernel, dim3(1), dim3(256), 0, st, cur, seqs);
+        PS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(mt_combine_kernel, dim3(JP), dim3(640), 0, st, seqs, jump_polys + (size_t)(CHUNK_LOG2 + b) * MT_N, nxt);
         PS_CHECK_LAUNCH();
         uint32_t *t = cur; cur = nxt; nxt = t;
     }
-    if (hipMemcpyAsync(states, cur, MT_N * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
+    if (hipMemcpyAsync(states, cur, WSZ * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
     // 3. doubling: states[2^m + r] = jump_{CHUNK * 2^m}(states[r])
     for (int m = 0; ((int64_t)1 << m) < K; ++m) {
         const int64_t have = (int64_t)1 << m;
         const int64_t make = (K - have) < have ? (K - have) : have;
-        hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)make), dim3(640), jump_lds, st, states,
-                           jump_polys + (size_t)(CHUNK_LOG2 + m) * MT_N, states + (size_t)have * MT_N);
+        hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)make), dim3(256), 0, st, states, seqs);
+        PS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(mt_combine_kernel, dim3((unsigned)(make * JP)), dim3(640), 0, st, seqs,
+                           jump_polys + (size_t)(CHUNK_LOG2 + m) * MT_N, states + (size_t)have * WSZ);
         PS_CHECK_LAUNCH();
     }
     // 4. chunks -> raw words; word 0 separately
