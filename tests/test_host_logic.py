@@ -102,3 +102,30 @@ def test_lsh_rotation_matrix_properties():
             np.testing.assert_allclose(A @ A.T, np.eye(nbits), atol=1e-5)
         else:
             np.testing.assert_allclose(A.T @ A, np.eye(d), atol=1e-5)   # tight frame
+
+
+def test_ingest_matches_reference_mapping_semantics(tmp_path):
+    """pinsage_hip.ingest vs a literal restatement of data/dataset.py:77-116 (dict of first appearances +
+    per-row lookups)."""
+    from pinsage_hip.ingest import build_graph_from_ratings, build_graph_from_csv
+    rs = np.random.RandomState(0)
+    users = rs.choice([7, 3, 99, 12, 5000, 42], size=200)
+    movies = rs.choice([1193, 661, 914, 3408, 2355, 1197, 1287, 2804], size=200)
+    ratings = rs.randint(1, 11, size=200) * 0.5
+    movie_map, user_map = {}, {}
+    for m in movies:
+        movie_map.setdefault(m, len(movie_map))
+    for u in users:
+        user_map.setdefault(u, len(user_map))
+    ui = torch.tensor([user_map[u] for u in users]) + len(movie_map)
+    mi = torch.tensor([movie_map[m] for m in movies])
+    ref_ei = torch.stack([torch.cat([ui, mi]), torch.cat([mi, ui])], dim=0)
+    ref_ew = torch.cat([torch.tensor(ratings, dtype=torch.float)] * 2)
+    ei, ew, mu, uu = build_graph_from_ratings(users, movies, ratings)
+    assert torch.equal(ei, ref_ei) and torch.equal(ew, ref_ew) and ei.dtype == torch.int64 and ew.dtype == torch.float32
+    assert list(mu) == list(movie_map) and list(uu) == list(user_map)
+    import pandas as pd
+    p = tmp_path / "ratings.csv"
+    pd.DataFrame({"userId": users, "movieId": movies, "rating": ratings, "timestamp": 0}).to_csv(p, index=False)
+    ei2, ew2, _, _ = build_graph_from_csv(str(p))
+    assert torch.equal(ei2, ref_ei) and torch.equal(ew2, ref_ew)
