@@ -179,15 +179,16 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const int32_t *__restri
 }
 
 // Queries per wave.  Small tiles need fewer table slices for the same number of waves (every slice pays its
-// own top-k warm-up); larger tiles would re-read the table from L2 less often, but measured on MI355X
-// (59 047 x 512-bit codes) 4 beats 8 / 16 / 32 for 10 K and for 59 K queries alike.
-int pick_tile(int64_t nq) {
+// own top-k warm-up): measured on MI355X with an L2-resident table (59 047 x 512 bit) 4 beats 8 / 16 / 32 for
+// 10 K and for 59 K queries alike.  A table far beyond the caches (>= 256 MB) is re-read from HBM once per tile,
+// so there the tile is 32 queries.
+int pick_tile(int64_t nq, int64_t table_bytes) {
     (void)nq;
-    return 4;
+    return table_bytes >= ((int64_t)256 << 20) ? 32 : 4;
 }
 
-int pick_splits(int64_t nq, int64_t N) {
-    const int qt = pick_tile(nq);
+int pick_splits(int64_t nq, int64_t N, int cs) {
+    const int qt = pick_tile(nq, N * cs);
     const int64_t tiles = (nq + qt - 1) / qt;
     int64_t s = (2048 + tiles - 1) / tiles;          // aim at >= 2048 waves
     if (s < 1) s = 1;
@@ -200,7 +201,7 @@ int pick_splits(int64_t nq, int64_t N) {
 
 extern "C" size_t ps_hamming_topk_workspace_bytes(int64_t nq, int64_t N, int cs, int k) {
     if (nq <= 0 || k <= 0) return 256;
-    const int s = pick_splits(nq, N);
+    const int s = pick_splits(nq, N, cs);
     return (size_t)s * (size_t)nq * (size_t)k * (sizeof(int32_t) + sizeof(int64_t)) + 512;
 }
 
@@ -228,7 +229,7 @@ extern "C" int ps_hamming_topk(const uint8_t *qcodes, int64_t nq, const uint8_t 
     if ((reinterpret_cast<size_t>(qcodes) | reinterpret_cast<size_t>(codes)) % 4 != 0) return PS_EINVAL;
     if (N >= ((int64_t)1 << 32)) return PS_EUNSUPPORTED;
     const int words = cs / 4;
-    const int s = pick_splits(nq, N);
+    const int s = pick_splits(nq, N, cs);
     hipStream_t st = ps_stream(stream);
     int32_t *cd = dist;
     int64_t *ci = ids;
@@ -239,7 +240,7 @@ extern "C" int ps_hamming_topk(const uint8_t *qcodes, int64_t nq, const uint8_t 
         ci = reinterpret_cast<int64_t *>(base);
         cd = reinterpret_cast<int32_t *>(base + (size_t)s * nq * k * sizeof(int64_t));
     }
-    const int QUERY_TILE = pick_tile(nq);
+    const int QUERY_TILE = pick_tile(nq, N * cs);
     const int64_t waves = ((nq + QUERY_TILE - 1) / QUERY_TILE) * s;
     const unsigned grid = (unsigned)ps_cdiv(waves, 4);
     int kcap = 16;

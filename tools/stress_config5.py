@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Single-GPU stress at a fraction of BASELINE configs[4] (100 M items / 1 B edges): graph build, philox
+sampling of every item, pooled forward on an item slice, LSH encode + top-11 scan over all items.
+Usage: python tools/stress_config5.py [--frac 0.25]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "movie-recommendation-engine_amd")); sys.path.insert(0, ROOT)
+import numpy as np, torch
+
+def sync_time(fn):
+    torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return r, time.perf_counter() - t
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--frac", type=float, default=0.25); a = ap.parse_args()
+    from pinsage_hip import synth, sampling, dense
+    from pinsage_hip.graph import DeviceGraph
+    from utils.random_walk import RandomWalkSampler
+    from model.pinsage import PinSage
+    dev = torch.device("cuda")
+    M, U, R = int(100e6 * a.frac), int(10e6 * a.frac), int(1e9 * a.frac)
+    print(f"frac {a.frac}: M={M} U={U} R={R} (directed edges {2*R})", flush=True)
+    (ei, ew), t = sync_time(lambda: synth.bipartite_ratings(U, M, R, device=dev)); print(f"synthetic ratings: {t:.2f}s", flush=True)
+    g, t = sync_time(lambda: DeviceGraph(ei, ew)); del ei, ew; torch.cuda.empty_cache()
+    print(f"DeviceGraph build: {t:.2f}s  V={g.V} E={g.E} maxdeg={g.max_degree} resident {g.nbytes()/1e9:.1f} GB; "
+          f"GPU mem in use {torch.cuda.memory_allocated()/1e9:.1f} GB", flush=True)
+    smp = RandomWalkSampler.from_graph(g, 2, 100, rng="philox", seed=42)
+    nodes = torch.arange(M, device=dev)
+    batches = []
+    for layer in range(2):
+        b, t = sync_time(lambda: smp.sample_batch(nodes, 10)); batches.append(b)
+        print(f"layer {layer} sampling of {M} items: {t*1e3:.1f} ms -> {M*200/t/1e9:.2f} G steps/s, {M/t/1e6:.1f} M items/s", flush=True)
+    assert int(batches[0].nvalid.min()) >= 1 and int(batches[0].ids.max()) < g.V
+    S = min(M, 2_000_000)                                   # pooled forward on an item slice (memory)
+    model = PinSage(128, 256, 256, 2).to(dev).eval()
+    x = torch.randn(S, 128, device=dev)
+    sl = [sampling.NeighborBatch(b.ids[:S].contiguous(), b.counts[:S].contiguous(), b.nvalid[:S].contiguous()) for b in batches]
+    lists = [(sampling.LazyNeighborList(b, "ids"), sampling.LazyNeighborList(b, "weights")) for b in sl]
+    with torch.no_grad():
+        emb, t = sync_time(lambda: model(x, None, [l[0] for l in lists], [l[1] for l in lists]))
+    print(f"pooled forward on {S} items (ids > {S-1} dropped like user ids): {t*1e3:.1f} ms -> {S/t/1e6:.1f} M items/s", flush=True)
+    del x, batches, sl, lists
+    A = torch.randn(512, 256, device=dev)
+    codes = torch.empty((M, 64), dtype=torch.uint8, device=dev)
+    t0 = time.perf_counter()
+    for s in range(0, M, 4_000_000):                        # encode random unit embeddings chunk by chunk
+        e = torch.nn.functional.normalize(torch.randn(min(4_000_000, M - s), 256, device=dev), dim=1)
+        codes[s:s + e.size(0)] = dense.lsh_encode(e, A)
+    torch.cuda.synchronize(); print(f"LSH encode of {M} items incl. generating inputs: {time.perf_counter()-t0:.2f}s", flush=True)
+    for nq in (1024, 16384):
+        (d, i), t = sync_time(lambda: dense.hamming_topk(codes[:nq], codes, 11))
+        assert bool((i[:, 0] == torch.arange(nq, device=dev)).all())
+        print(f"top-11 of {nq} queries over {M} codes (1.6 GB x frac table): {t*1e3:.1f} ms -> {nq/t/1e3:.1f} K queries/s, "
+              f"{nq*M*64/t/1e12:.1f} TB/s logical", flush=True)
+    print(f"peak GPU memory {torch.cuda.max_memory_allocated()/1e9:.1f} GB", flush=True)
+
+if __name__ == "__main__":
+    main()
