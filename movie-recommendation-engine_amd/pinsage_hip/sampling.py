@@ -116,10 +116,14 @@ def draw_numpy_uniforms(n, device):
     return t.to(device, non_blocking=True)
 
 
-def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None, use_guide=True, use_packed=True):
+def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None, use_guide=True, use_packed=True,
+                stream_nodes=None):
     """batch_sample_neighbors on the device.  rng='numpy': the global numpy stream (bit-exact with
     the reference; needs a graph without reachable sinks); rng='philox': counter-based.
-    `uniforms` (device fp64) overrides the numpy draw (tests / multi-GPU shards)."""
+    `uniforms` (device fp64) overrides the numpy draw (tests).  `stream_nodes` (rng='numpy' only): the complete
+    start-node sequence of the logical batch this call is a contiguous slice of (item shards): the stream offsets
+    are computed over all of them and the whole batch's uniforms are drawn, so the ids/counts equal the matching
+    rows of the unsharded call and the global np.random state ends where the unsharded call leaves it."""
     dev = graph.device
     starts = _nodes_tensor(nodes, dev, graph.V)
     B = int(starts.numel())
@@ -134,10 +138,18 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
                     "rng='numpy' needs a graph in which every edge points at a node with out-edges (true for "
                     "the reference's bidirectional graph builders); on graphs with reachable sinks the "
                     "reference's RNG consumption is data dependent -- use rng='philox'")
-            uoff = torch.empty(B, dtype=torch.int64, device=dev)
             total = torch.empty(1, dtype=torch.int64, device=dev)
-            nv.call("ps_uniform_offsets", nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(starts), nv.i64(B),
-                                           nv.i32(W), nv.i32(L), nv.ptr(uoff), nv.ptr(total), nv.stream())
+            if stream_nodes is not None:
+                all_nodes, lo = stream_nodes
+                all_nodes = _nodes_tensor(all_nodes, dev, graph.V)
+                uoff_all = torch.empty(all_nodes.numel(), dtype=torch.int64, device=dev)
+                nv.call("ps_uniform_offsets", nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(all_nodes),
+                        nv.i64(all_nodes.numel()), nv.i32(W), nv.i32(L), nv.ptr(uoff_all), nv.ptr(total), nv.stream())
+                uoff = uoff_all[lo:lo + B].contiguous()
+            else:
+                uoff = torch.empty(B, dtype=torch.int64, device=dev)
+                nv.call("ps_uniform_offsets", nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(starts), nv.i64(B),
+                        nv.i32(W), nv.i32(L), nv.ptr(uoff), nv.ptr(total), nv.stream())
             if uniforms is None:
                 n = int(total.item())
                 uniforms = draw_numpy_uniforms(n, dev)

@@ -72,7 +72,13 @@ def all_gather_rows(t, chunk, group=None):
 class HipOps:
     """The production backend: thin names over the C-ABI wrappers."""
 
-    def sample(self, sampler, nodes, T):
+    def sample(self, sampler, nodes, T, shard=None):
+        """shard = (num_items, lo): with the numpy-stream RNG every rank draws the whole catalogue's uniforms
+        (same np.random seed on all ranks) and indexes them with the global offsets of its own nodes."""
+        if shard is not None and getattr(sampler, "rng", None) == "numpy":
+            M, lo = shard
+            all_nodes = torch.arange(M, dtype=torch.int64, device=nodes.device)
+            return sampler.sample_batch(nodes, T, stream_nodes=(all_nodes, lo))
         return sampler.sample_batch(nodes, T)
 
     def pool(self, h_full, batch, max_idx):
@@ -105,6 +111,12 @@ class ShardedPinSage:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.lo, self.hi, self.chunk = shard_range(self.M, self.rank, self.world)
 
+    def _sample(self, nodes, T, shard):
+        try:
+            return self.ops.sample(self.sampler, nodes, T, shard)
+        except TypeError:                      # test backends with the 3-argument signature
+            return self.ops.sample(self.sampler, nodes, T)
+
     # -- embeddings: PinSage.get_embeddings (model/pinsage.py:253-280) for the local item range ------
     def embed(self, x_local, T, x_full=None):
         """x_local: this rank's feature rows.  x_full (optional, replicated [M, F] features): layer-0 hidden
@@ -114,7 +126,8 @@ class ShardedPinSage:
         nodes = torch.arange(self.lo, self.hi, dtype=torch.int64, device=dev)
         # fresh neighbour samples per layer, drawn in the reference's order (:271-275); no communication.
         # Layer i+1's sampling and lin_self are enqueued while layer i's hidden rows are being all-gathered.
-        batch = ops.sample(self.sampler, nodes, T)
+        shard = (self.M, self.lo) if self.world > 1 else None
+        batch = self._sample(nodes, T, shard)
         if x_full is not None and self.world > 1:
             h_all = ops.linear(x_full, P["input_proj.weight"], P["input_proj.bias"], relu=True)
             h = h_all[self.lo:self.hi]
@@ -123,7 +136,7 @@ class ShardedPinSage:
             h = ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
             pending = all_gather_rows_async(h, self.chunk, self.group)
         for i in range(self.num_layers):
-            next_batch = ops.sample(self.sampler, nodes, T) if i + 1 < self.num_layers else None
+            next_batch = self._sample(nodes, T, shard) if i + 1 < self.num_layers else None
             H = h.size(1)
             h_self = ops.linear(h, P[f"convs.{i}.lin_self.weight"], P[f"convs.{i}.lin_self.bias"])
             h_full = pending.wait()                                          # the per-layer exchange

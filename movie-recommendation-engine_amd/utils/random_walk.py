@@ -59,12 +59,14 @@ class RandomWalkSampler:
         return self._adj_list
 
     # ---- tensor-native API (what model.pinsage uses) -------------------------------------
-    def sample_batch(self, nodes, num_neighbors=10, uniforms=None):
-        """-> sampling.NeighborBatch on the device (ids / visit counts / nvalid)."""
+    def sample_batch(self, nodes, num_neighbors=10, uniforms=None, stream_nodes=None):
+        """-> sampling.NeighborBatch on the device (ids / visit counts / nvalid).  `stream_nodes=(all_nodes, lo)`:
+        `nodes` is the slice all_nodes[lo:lo+len(nodes)] of a larger logical batch (item shards, rng='numpy')."""
         call = self._calls
         self._calls += 1
         return sampling.walk_sample(self.graph, nodes, int(num_neighbors), W=self.num_walks, L=self.walk_length,
-                                    rng=self.rng, seed=self.seed, call=call, uniforms=uniforms)
+                                    rng=self.rng, seed=self.seed, call=call, uniforms=uniforms,
+                                    stream_nodes=stream_nodes if self.rng == "numpy" else None)
 
     def single_walks(self, start_nodes):
         """Batched _single_walk: int32[B, walk_length] device tensor (-1 after a sink)."""

@@ -178,3 +178,31 @@ def test_guide_table_is_exact_on_skewed_weights():
     for x in (a, b, c):
         assert np.array_equal(x.ids.cpu().numpy(), ids) and np.array_equal(x.counts.cpu().numpy(), counts)
         assert np.array_equal(x.nvalid.cpu().numpy(), nv)
+
+
+def test_numpy_stream_mode_is_shard_invariant():
+    """rng='numpy' under item sharding: every 'rank' draws the whole batch's uniforms and uses the global
+    stream offsets of its own slice -> rows identical to the unsharded call, same final np.random state."""
+    from pinsage_hip.shard import HipOps
+    from utils.random_walk import RandomWalkSampler
+    ei, ew = bipartite_graph(3000, 2000, 150000, 17, "half")
+    # a few isolated items inside the catalogue (no ratings): they consume no uniforms
+    keep = ~np.isin(ei[1][: ei.shape[1] // 2], [5, 1500, 2999])
+    keep2 = np.concatenate([keep, keep])
+    ei, ew = ei[:, keep2], ew[keep2]
+    s = RandomWalkSampler(torch.from_numpy(ei), torch.from_numpy(ew), walk_length=2, num_walks=100)
+    M = 3000
+    dev = s.graph.device
+    np.random.seed(77)
+    full = s.sample_batch(torch.arange(M, device=dev), 10)
+    tail = np.random.random_sample()
+    assert int((full.nvalid == 0).sum()) == 3
+    ops = HipOps()
+    for world in (2, 3):
+        chunk = (M + world - 1) // world
+        for r in range(world):
+            lo, hi = r * chunk, min((r + 1) * chunk, M)
+            np.random.seed(77)
+            part = ops.sample(s, torch.arange(lo, hi, device=dev), 10, shard=(M, lo))
+            assert torch.equal(part.ids, full.ids[lo:hi]) and torch.equal(part.counts, full.counts[lo:hi])
+            assert np.random.random_sample() == tail
