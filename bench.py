@@ -179,6 +179,7 @@ def main():
         # ROCm (~46 per step), so this region is slower than the clean one and is NOT used for `value`.
         timer = nv.KernelTimer()
         recs = []
+        pipe.overlap_sampling = False       # per-kernel durations are measured with the kernels running alone
         sync_all()
         nv.set_timer(timer)
         t1 = time.perf_counter()
@@ -187,6 +188,7 @@ def main():
         sync_all()
         elapsed_instr = time.perf_counter() - t1
         nv.set_timer(None)
+        pipe.overlap_sampling = True
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -211,7 +213,9 @@ def main():
         b0 = sampling.walk_sample(graph, nodes, T, W, L, rng="philox", seed=42, call=0)
         valid = ((b0.ids >= 0) & (b0.ids <= M - 1)).sum().item()
         pool_bytes = valid * HID * 4 + n_loc * HID * 4 + n_loc * T * 8
-        lin_flops_step = 2.0 * n_loc * (F_IN * HID + LAYERS * (HID * HID + 2 * HID * HID) + HID * D)
+        # executed flops: lin_self is composed into lin_update once per forward (2 * H^3 + 2 * H^2 per layer),
+        # so per item: input_proj + layers * (h W'^T + h_neigh Wu2^T) + output_proj
+        lin_flops_step = 2.0 * n_loc * (F_IN * HID + LAYERS * (2 * HID * HID) + HID * D) + LAYERS * (2.0 * HID ** 3 + 2.0 * HID * HID)
         enc_flops = 2.0 * D * nbits                              # per encoded row
         kern = {}
 

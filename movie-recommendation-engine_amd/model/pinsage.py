@@ -24,6 +24,9 @@ import torch.nn.functional as F
 
 from pinsage_hip import dense, sampling
 from pinsage_hip import native as nv
+from pinsage_hip.shard import HipOps, fused_self_update
+
+_OPS = HipOps()
 
 
 class GraphConv(nn.Module):
@@ -245,11 +248,11 @@ class PinSage(nn.Module):
                 raise RuntimeError(f"Sizes of tensors must match except in dimension 1. Expected size {h.size(0)} "
                                    f"but got size {h_neigh.size(0)} for tensor number 1 in the list.")
             H = h.size(1)
-            h_self = dense.linear(h, P[f"convs.{i}.lin_self.weight"], P[f"convs.{i}.lin_self.bias"])
             Wu = P[f"convs.{i}.lin_update.weight"]
-            # cat([h_self, h_neigh]) @ Wu.T == h_self @ Wu[:, :H].T + h_neigh @ Wu[:, H:].T  (:238-240)
-            h = dense.linear(h_self, Wu[:, :H], P[f"convs.{i}.lin_update.bias"], x2=h_neigh, W2=Wu[:, H:],
-                             relu=True, l2norm=True)
+            # cat([lin_self(h), h_neigh]) @ Wu.T + bu == h @ (Wu[:, :H] Ws).T + h_neigh @ Wu[:, H:].T + (Wu[:, :H] bs + bu)
+            # (:235-240): the stacked self path is composed once per forward, the cat never materialises
+            W1, b1 = fused_self_update(_OPS, P, i, H)
+            h = dense.linear(h, W1, b1, x2=h_neigh, W2=Wu[:, H:], relu=True, l2norm=True)
         e = dense.linear(h, P["output_proj.weight"], P["output_proj.bias"], l2norm=True)
         return e if x.is_cuda else e.to(x.device)
 

@@ -88,9 +88,15 @@ def _run(rank, world, port, out):
         from pinsage_hip.shard import ShardedPinSage, all_gather_rows
         cg, params, x, A = _setup()
         pipe = ShardedPinSage(params, 2, _Sampler(cg, 77), M, ops=OracleOps())
+        pipe.fuse_self = False                  # exact orchestration check against the unfused oracle forward
+        fused = ShardedPinSage(params, 2, _Sampler(cg, 77), M, ops=OracleOps())
+        emb_f = fused.embed(x[fused.lo:fused.hi], T)          # composed lin_self/lin_update: fp32-rounding close
         emb = pipe.embed(x[pipe.lo:pipe.hi], T, x_full=x if rank == 0 else x.clone())   # replicated-feature path
-        emb_b = ShardedPinSage(params, 2, _Sampler(cg, 77), M, ops=OracleOps()).embed(x[pipe.lo:pipe.hi], T)
+        pipe_b = ShardedPinSage(params, 2, _Sampler(cg, 77), M, ops=OracleOps())
+        pipe_b.fuse_self = False
+        emb_b = pipe_b.embed(x[pipe.lo:pipe.hi], T)
         assert torch.equal(emb, emb_b)                       # all-gathered layer-0 rows == recomputed ones
+        assert torch.allclose(emb_f, emb, rtol=1e-5, atol=2e-6)
         codes = pipe.build_index(emb, A)
         nq_local = 8
         d, i = pipe.search(emb[:nq_local], K)
