@@ -19,6 +19,12 @@ def _rowmajor(w):
     return w, int(w.stride(0)) if w.size(0) > 1 else max(int(w.stride(0)), int(w.size(1)))
 
 
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise nv.NativeError("libpinsage_hip takes device (HBM) tensors; got a CPU tensor (no CPU fallback)")
+
+
 def _ptr_view(t):
     if t is None:
         return nv.C.c_void_p(0)
@@ -30,6 +36,7 @@ def _ptr_view(t):
 def linear(x, W, b=None, x2=None, W2=None, relu=False, l2norm=False):
     """y = epi(x @ W.T (+ x2 @ W2.T) + b): nn.Linear / F.relu / torch.cat / F.normalize of
     PinSage.forward (reference model/pinsage.py:202,235-240,248-249) in one kernel."""
+    _require_cuda(x, W, b, x2, W2)
     x = x.contiguous()
     if x.dtype != torch.float32:
         raise TypeError("fp32 expected")
@@ -58,6 +65,7 @@ def linear(x, W, b=None, x2=None, W2=None, relu=False, l2norm=False):
 
 def lsh_encode(x, A):
     """codes uint8[n, nbits/8]: bit j = (x . A[j] >= 0), LSB first (faiss IndexLSH.sa_encode)."""
+    _require_cuda(x, A)
     x = x.contiguous()
     A = A.contiguous()
     n, d = int(x.size(0)), int(x.size(1))
@@ -73,6 +81,7 @@ def lsh_encode(x, A):
 
 def hamming_topk(qcodes, codes, k, id_offset=0):
     """-> (dist int32[nq,k], ids int64[nq,k]): k smallest by (distance, id), ascending."""
+    _require_cuda(qcodes, codes)
     qcodes = qcodes.contiguous()
     codes = codes.contiguous()
     nq, cs = int(qcodes.size(0)), int(qcodes.size(1))

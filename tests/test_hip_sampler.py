@@ -206,3 +206,30 @@ def test_numpy_stream_mode_is_shard_invariant():
             part = ops.sample(s, torch.arange(lo, hi, device=dev), 10, shard=(M, lo))
             assert torch.equal(part.ids, full.ids[lo:hi]) and torch.equal(part.counts, full.counts[lo:hi])
             assert np.random.random_sample() == tail
+
+
+def test_error_paths_raise_loudly():
+    """Unsupported shapes / bad arguments come back as exceptions, never as silent fallbacks."""
+    from pinsage_hip import native, sampling, dense
+    from utils.random_walk import RandomWalkSampler
+    from utils.nearest_neighbors import LSHIndex
+    ei, ew = bipartite_graph(50, 40, 600, 2, "half")
+    s = RandomWalkSampler(torch.from_numpy(ei), torch.from_numpy(ew), walk_length=11, num_walks=100, rng="philox")
+    with pytest.raises(native.NativeError, match="unsupported"):
+        s.sample_batch([0, 1], 5)                                   # W * L = 1100 > 1024 positions per wave
+    with pytest.raises(ValueError):
+        sampling.walk_sample(s.graph, [0], 5, rng="xorshift")
+    with pytest.raises(ValueError):
+        RandomWalkSampler(torch.zeros((3, 4), dtype=torch.int64))   # edge_index must be [2, E]
+    with pytest.raises(native.NativeError):
+        dense.linear(torch.zeros(4, 8), torch.zeros(3, 8))          # host tensors are not device pointers
+    with pytest.raises(ValueError):
+        dense.linear(torch.zeros(4, 8, device="cuda"), torch.zeros(3, 7, device="cuda"))
+    with pytest.raises(ValueError):
+        LSHIndex(16, 2048, 16)                                      # > 1024 bits
+    idx = LSHIndex(16, 64, 16)
+    idx.build(torch.randn(10, 16))
+    with pytest.raises(AssertionError):
+        idx.search(torch.randn(2, 15), 3)                           # wrong dimensionality
+    with pytest.raises(native.NativeError, match="unsupported"):
+        idx.search(torch.randn(2, 16), 100)                         # k > 64
