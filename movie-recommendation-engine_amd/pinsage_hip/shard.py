@@ -69,15 +69,26 @@ def all_gather_rows(t, chunk, group=None):
     return all_gather_rows_async(t, chunk, group).wait()
 
 
+_FUSED_CACHE = {}
+
+
 def fused_self_update(ops, P, i, H):
     """lin_update(cat[lin_self(h), h_neigh]) = h (Wu1 Ws)^T + h_neigh Wu2^T + (Wu1 bs + bu)  (model/pinsage.py:235-239):
     the two stacked linear maps on the self path are composed once per forward (a 256^3 GEMM) instead of applied
     to every row; identical up to fp32 rounding (checked against the reference goldens at 1e-5)."""
     Ws, bs = P[f"convs.{i}.lin_self.weight"], P[f"convs.{i}.lin_self.bias"]
     Wu, bu = P[f"convs.{i}.lin_update.weight"], P[f"convs.{i}.lin_update.bias"]
+    # weight preprocessing, reused while the four parameter tensors are unchanged (same storage, same version)
+    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (Ws, bs, Wu, bu)) + (type(ops).__name__,)
+    hit = _FUSED_CACHE.get(key)
+    if hit is not None:
+        return hit
     Wu1 = Wu[:, :H]
     W1 = ops.linear(Wu1.contiguous(), Ws.t().contiguous(), None)            # [H_out, H_in] = Wu1 @ Ws
     b1 = ops.linear(bs.reshape(1, -1).contiguous(), Wu1.contiguous(), bu).reshape(-1)   # Wu1 @ bs + bu
+    if len(_FUSED_CACHE) > 64:
+        _FUSED_CACHE.clear()
+    _FUSED_CACHE[key] = (W1, b1)
     return W1, b1
 
 

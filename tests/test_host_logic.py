@@ -129,3 +129,33 @@ def test_ingest_matches_reference_mapping_semantics(tmp_path):
     pd.DataFrame({"userId": users, "movieId": movies, "rating": ratings, "timestamp": 0}).to_csv(p, index=False)
     ei2, ew2, _, _ = build_graph_from_csv(str(p))
     assert torch.equal(ei2, ref_ei) and torch.equal(ew2, ref_ew)
+
+
+def test_fused_weight_cache_tracks_parameter_updates():
+    """The composed (lin_update o lin_self) weights are cached per parameter version: an in-place update of any
+    of the four tensors (an optimizer step) must invalidate the cache."""
+    from pinsage_hip import shard
+
+    class Ops:
+        calls = 0
+
+        def linear(self, x, W, b, **kw):
+            Ops.calls += 1
+            y = x @ W.t()
+            return y if b is None else y + b
+
+    H = 8
+    P = {"convs.0.lin_self.weight": torch.randn(H, H), "convs.0.lin_self.bias": torch.randn(H),
+         "convs.0.lin_update.weight": torch.randn(H, 2 * H), "convs.0.lin_update.bias": torch.randn(H)}
+    ops = Ops()
+    W1, b1 = shard.fused_self_update(ops, P, 0, H)
+    assert Ops.calls == 2
+    h = torch.randn(5, H)
+    ref = (h @ P["convs.0.lin_self.weight"].t() + P["convs.0.lin_self.bias"]) @ P["convs.0.lin_update.weight"][:, :H].t() \
+        + P["convs.0.lin_update.bias"]
+    assert torch.allclose(h @ W1.t() + b1, ref, atol=1e-5)
+    shard.fused_self_update(ops, P, 0, H)
+    assert Ops.calls == 2                                   # cache hit
+    P["convs.0.lin_self.bias"].add_(1.0)                    # in-place update bumps the version counter
+    W2, b2 = shard.fused_self_update(ops, P, 0, H)
+    assert Ops.calls == 4 and not torch.equal(b2, b1)
