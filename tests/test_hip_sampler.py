@@ -233,3 +233,48 @@ def test_error_paths_raise_loudly():
         idx.search(torch.randn(2, 15), 3)                           # wrong dimensionality
     with pytest.raises(native.NativeError, match="unsupported"):
         idx.search(torch.randn(2, 16), 100)                         # k > 64
+
+
+def test_hard_negatives_match_reference_semantics():
+    """pinsage_hip.negatives.sample_hard_negatives vs a literal restatement of data/negative_sampler.py:44-99 on
+    the oracle's `_single_walk` (same global numpy stream): identical indices and final RNG state, for the
+    reference's default rank window (always the random fallback: 100 walks visit < 2000 nodes) and a narrow one."""
+    from oracle import c_oracle as co
+    from pinsage_hip.negatives import sample_hard_negatives
+    from utils.random_walk import RandomWalkSampler
+    ei, ew = bipartite_graph(300, 200, 9000, 23, "half")
+    M = 300
+    cg = co.Graph(ei, ew)
+    s = RandomWalkSampler(torch.from_numpy(ei), torch.from_numpy(ew), walk_length=2, num_walks=7)
+    queries = torch.tensor([5, 17, 299, 0, 123])
+
+    def reference(min_rank, max_rank, num_hard):
+        out = []
+        for idx in queries.numpy():
+            visited = {}
+            for _ in range(100):
+                u = np.random.random_sample(2)                         # two taken steps per walk on this graph
+                walk, _ = co.single_walk(cg, int(idx), 2, u, 0)
+                for node in walk[1:]:
+                    visited[node] = visited.get(node, 0) + 1
+            ranked = sorted(visited.items(), key=lambda x: x[1], reverse=True)
+            cand = [item for item, _ in ranked[min_rank:max_rank] if item in range(M)]
+            if not cand:
+                smp = np.random.choice(list(range(M)), size=num_hard, replace=False)
+            else:
+                smp = np.random.choice(cand, size=min(num_hard, len(cand)), replace=False)
+                if len(smp) < num_hard:
+                    add = np.random.choice([i for i in range(M) if i not in smp], size=num_hard - len(smp), replace=False)
+                    smp = np.concatenate([smp, add])
+            out.append(smp)
+        return np.asarray(out)
+
+    for (lo, hi, nh) in ((2000, 5000, 5), (3, 40, 4), (60, 64, 6)):
+        np.random.seed(31)
+        ref = reference(lo, hi, nh)
+        tail = np.random.random_sample()
+        np.random.seed(31)
+        got = sample_hard_negatives(s, M, queries, num_hard_samples=nh, max_rank=hi, min_rank=lo)
+        assert got.shape == (5, nh) and got.dtype == torch.int64
+        assert np.array_equal(got.numpy(), ref), (lo, hi)
+        assert np.random.random_sample() == tail
