@@ -162,9 +162,18 @@ def main():
         # settle: the first ~100 ms after idle run at a lower clock (measured: 5.0 ms/step after 3 steps
         # vs 3.6 ms/step after 30); run untimed steps for >= 0.5 s, then the W warm-up steps proper
         t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < 0.5:
-            step()
+        while True:
+            for _ in range(10):
+                step()
             torch.cuda.synchronize()
+            # every step contains collectives, so all ranks must run the same number of settle steps: rank 0
+            # decides, everybody follows
+            go_on = torch.tensor([1 if time.perf_counter() - t_settle < 0.5 else 0], dtype=torch.int32,
+                                 device=dev if backend == "nccl" else "cpu")
+            if world > 1:
+                dist.broadcast(go_on, src=0)
+            if int(go_on.item()) == 0:
+                break
         for _ in range(a.warmup):
             step()
         # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
