@@ -82,13 +82,15 @@ def fused_self_update(ops, P, i, H):
     key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (Ws, bs, Wu, bu)) + (type(ops).__name__,)
     hit = _FUSED_CACHE.get(key)
     if hit is not None:
-        return hit
+        return hit[0], hit[1]
     Wu1 = Wu[:, :H]
     W1 = ops.linear(Wu1.contiguous(), Ws.t().contiguous(), None)            # [H_out, H_in] = Wu1 @ Ws
     b1 = ops.linear(bs.reshape(1, -1).contiguous(), Wu1.contiguous(), bu).reshape(-1)   # Wu1 @ bs + bu
     if len(_FUSED_CACHE) > 64:
         _FUSED_CACHE.clear()
-    _FUSED_CACHE[key] = (W1, b1)
+    # the entry keeps the four source tensors alive: their storage cannot be freed and handed to another model,
+    # so (address, version) identifies the weights for as long as the entry exists
+    _FUSED_CACHE[key] = (W1, b1, (Ws, bs, Wu, bu))
     return W1, b1
 
 
