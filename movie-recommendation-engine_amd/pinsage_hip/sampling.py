@@ -49,11 +49,15 @@ class LazyNeighborList(list):
     """A real `list` (isinstance checks in the reference pass) whose items are produced from the
     device batch on first python-level access.  Our own kernels read `.batch` and never touch it."""
 
+    EAGER_BELOW = 4096
+
     def __init__(self, batch: NeighborBatch, kind: str):
         super().__init__()
         self.batch = batch
         self.kind = kind
         self._done = False
+        if batch.B <= self.EAGER_BELOW:       # small batches: a plain, fully populated list (C-level consumers too)
+            self._fill()
 
     def _fill(self):
         if not self._done:

@@ -27,7 +27,11 @@ def test_lazy_neighbor_list_is_a_list():
     cnt = torch.tensor([[3, 1, 0], [5, 0, 0], [0, 0, 0]], dtype=torch.int32)
     b = NeighborBatch(ids, cnt, torch.tensor([2, 1, 0], dtype=torch.int32))
     nb, wt = LazyNeighborList(b, "ids"), LazyNeighborList(b, "weights")
-    assert isinstance(nb, list) and len(nb) == 3 and not nb._done
+    assert isinstance(nb, list) and len(nb) == 3 and nb._done and list.__len__(nb) == 3     # small: eager
+    LazyNeighborList.EAGER_BELOW = 0
+    lazy = LazyNeighborList(b, "ids")
+    assert not lazy._done and len(lazy) == 3 and [len(r) for r in lazy] == [2, 1, 0] and lazy._done
+    LazyNeighborList.EAGER_BELOW = 4096
     assert [list(map(int, r)) for r in nb] == [[4, 9], [7], []]
     assert all(isinstance(v, np.integer) for v in nb[0])
     assert wt[0] == [3 / 4, 1 / 4] and wt[1] == [1.0] and wt[2] == []
