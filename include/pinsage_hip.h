@@ -171,6 +171,15 @@ int ps_l2_topk(const float *X, int64_t N, int D, const float *Q, int64_t nq, int
                const uint32_t *probe, int words, float *dist, int64_t *ids, void *workspace,
                size_t workspace_bytes, ps_stream_t stream);
 
+/* ---- next row: the aggregation of GraphConv.propagate (model/pinsage.py:53-54, 70-92; PyG
+ * MessagePassing, aggr='add', flow source->target): out[r] = sum over the edges e of CSR row r of val[e] * x[col[e]].
+ * rowptr int64[V+1] / col int32[E] = edges grouped by TARGET node (ps_csr_build with the edge_index rows swapped),
+ * val float[E] = edge_weight * importance_weight in that order, or NULL (= 1); x float[N,H]; out float[V,H]
+ * (rowptr[V] == E).  fp32 accumulation in edge order inside a 512-edge slice; rows cut by a slice are combined with
+ * atomics, so long rows are reproducible only up to fp32 re-association, like PyG's scatter-add. */
+int ps_spmm_csr(const int64_t *rowptr, const int32_t *col, const float *val, const float *x, int64_t N, int H,
+                int64_t V, int64_t E, float *out, ps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,8 @@ What runs where
         bias/ReLU/concat/L2-normalise fused); with autograd enabled the same kernel does the
         pooling forward and torch does the (differentiable) dense layers.
   MLP branch (:205-214, what train.py uses)           -> plain torch nn.Linear (autograd), as in the reference.
-  edge_index branch (:243-245, GraphConv)             -> torch index_add ("next").
+  edge_index branch (:243-245, GraphConv)             -> ps_spmm_csr over the edges grouped by target node (no grad),
+        torch index_add_ when autograd is needed.
 """
 from __future__ import annotations
 
@@ -23,10 +24,24 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from pinsage_hip import dense, sampling
+from pinsage_hip import graph as graph_mod
 from pinsage_hip import native as nv
 from pinsage_hip.shard import HipOps, fused_self_update
 
 _OPS = HipOps()
+_TCSR_CACHE = {}
+
+
+def _target_csr(edge_index, num_nodes):
+    """TargetCSR of an edge_index tensor, cached while that tensor is alive and unmodified."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes))
+    hit = _TCSR_CACHE.get(key)
+    if hit is None:
+        if len(_TCSR_CACHE) > 8:
+            _TCSR_CACHE.clear()
+        hit = (graph_mod.TargetCSR(edge_index, num_nodes), edge_index)      # keeps edge_index alive: no address reuse
+        _TCSR_CACHE[key] = hit
+    return hit[0]
 
 
 class GraphConv(nn.Module):
@@ -54,6 +69,19 @@ class GraphConv(nn.Module):
         """aggr='add', flow source->target: out[dst] += message(x[src])."""
         if not isinstance(edge_index, torch.Tensor):
             raise TypeError("edge_index must be a LongTensor of shape [2, num_edges]")
+        if x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or
+                                                             any(p.requires_grad for p in self.parameters()))):
+            # inference on the GPU: CSR row gather-reduce (ps_spmm_csr) over the edges grouped by target node
+            tc = _target_csr(edge_index, int(x.size(0)))
+            val = None
+            if edge_weight is not None or importance_weights is not None:
+                w = torch.ones(tc.E, dtype=torch.float32, device=x.device)
+                if edge_weight is not None:
+                    w = w * edge_weight.to(x.device).float().view(-1)
+                if importance_weights is not None:
+                    w = w * importance_weights.to(x.device).float().view(-1)
+                val = w[tc.perm].contiguous()
+            return graph_mod.spmm_csr(tc, x.float(), val)
         src, dst = edge_index[0], edge_index[1]
         msg = self.message(x[src], edge_weight=edge_weight, importance_weights=importance_weights)
         out = torch.zeros_like(x)

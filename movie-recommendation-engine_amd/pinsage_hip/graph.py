@@ -67,3 +67,44 @@ class DeviceGraph:
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.cdf, self.nodeinfo, self.guide, self.packed))
+
+
+class TargetCSR:
+    """Edges grouped by target node (what GraphConv.propagate aggregates over): rowptr / col (= source node) /
+    perm (position of every CSR slot in the original edge order, for per-edge weights).  Built with the same
+    stable sort as the sampler's adjacency; cached per edge_index tensor by the caller."""
+
+    def __init__(self, edge_index, num_nodes):
+        dev = nv.require_gpu() if not edge_index.is_cuda else edge_index.device
+        ei = edge_index.to(device=dev, dtype=torch.int64)
+        E, V = int(ei.size(1)), int(num_nodes)
+        src, dst = ei[0].contiguous(), ei[1].contiguous()
+        self.V, self.E, self.device = V, E, dev
+        self.rowptr = torch.empty(V + 1, dtype=torch.int64, device=dev)
+        self.col = torch.empty(E, dtype=torch.int32, device=dev)
+        order = torch.empty(E, dtype=torch.float64, device=dev)
+        L = nv.lib()
+        wsb = int(L.ps_csr_build_workspace_bytes(nv.i64(E), nv.i64(V)))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        # the "weight" channel carries the original edge number (exact in fp32 only below 2^24, so it is passed
+        # through the fp64 output by building it in two halves)
+        idx = torch.arange(E, device=dev)
+        lo16 = (idx & 0xFFFF).to(torch.float32).contiguous()
+        hi16 = (idx >> 16).to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            nv.call("ps_csr_build", nv.ptr(dst), nv.ptr(src), nv.ptr(lo16), nv.i64(E), nv.i64(V), nv.ptr(self.rowptr),
+                    nv.ptr(self.col), nv.ptr(order), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
+            lo_sorted = order.clone()
+            nv.call("ps_csr_build", nv.ptr(dst), nv.ptr(src), nv.ptr(hi16), nv.i64(E), nv.i64(V), nv.ptr(self.rowptr),
+                    nv.ptr(self.col), nv.ptr(order), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
+        self.perm = (order.to(torch.int64) << 16) | lo_sorted.to(torch.int64)
+
+
+def spmm_csr(tcsr, x, val=None):
+    """out[r] = sum_e val[e] * x[col[e]] over row r of a TargetCSR (val in CSR slot order)."""
+    x = x.contiguous()
+    out = torch.empty((tcsr.V, int(x.size(1))), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        nv.call("ps_spmm_csr", nv.ptr(tcsr.rowptr), nv.ptr(tcsr.col), nv.ptr(val), nv.ptr(x), nv.i64(int(x.size(0))),
+                nv.i32(int(x.size(1))), nv.i64(tcsr.V), nv.i64(tcsr.E), nv.ptr(out), nv.stream())
+    return out
