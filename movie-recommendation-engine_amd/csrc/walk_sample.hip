@@ -84,6 +84,29 @@ __device__ __forceinline__ int32_t edge_col(const int32_t *col, const unsigned c
     return packed ? reinterpret_cast<const int32_t *>(packed + (size_t)(e >> 3) * 128 + 64)[e & 7] : col[e];
 }
 
+// cdf[e], cdf[e + 1] with one 16-byte load per lane (8-byte aligned; inside a packed block the pair must not
+// leave the block's 8 CDF slots)
+struct __attribute__((packed, aligned(8))) CdfPair { double c0, c1; };
+__device__ __forceinline__ bool cdf_pair_ok(const unsigned char *packed, eidx_t e) { return !packed || (e & 7) < 7; }
+__device__ __forceinline__ void edge_cdf_pair(const double *cdf, const unsigned char *packed, eidx_t e, double &c0,
+                                              double &c1) {
+    const CdfPair *p = packed ? reinterpret_cast<const CdfPair *>(packed + (size_t)(e >> 3) * 128 + (e & 7) * 8)
+                              : reinterpret_cast<const CdfPair *>(cdf + e);
+    const CdfPair v = *p;
+    c0 = v.c0;
+    c1 = v.c1;
+}
+
+struct __attribute__((packed, aligned(4))) ColPair { int32_t k0, k1; };
+__device__ __forceinline__ void edge_col_pair(const int32_t *col, const unsigned char *packed, eidx_t e, int32_t &k0,
+                                              int32_t &k1) {
+    const ColPair *p = packed ? reinterpret_cast<const ColPair *>(packed + (size_t)(e >> 3) * 128 + 64 + (e & 7) * 4)
+                              : reinterpret_cast<const ColPair *>(col + e);
+    const ColPair v = *p;
+    k0 = v.k0;
+    k1 = v.k1;
+}
+
 // Start state of searchsorted(cdf[lo:hi], u, 'right'): with a guide table the search starts at the bucket
 // floor(u * deg) (guide = #{cdf <= (j-1)/deg} <= answer) and first scans forward; `n` counts probes.
 __device__ __forceinline__ void search_init(const int32_t *guide, const unsigned char *packed, eidx_t lo, eidx_t hi,
@@ -166,9 +189,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                 int nA_ = 0, nB_ = 0;
                 if (aliveA) { search_init(a.guide, a.packed, loA, hiA, uA, lA, nA_); hA = hiA; }
                 if (aliveB) { search_init(a.guide, a.packed, loB, hiB, uB, lB, nB_); hB = hiB; }
-                // searchsorted(cdf, u, side='right') for both walks.  While scanning forward from the guide
-                // start, each iteration looks at two consecutive entries (and their destinations): the loads
-                // are independent, so the dependent chain is half as long; after LIN_PROBES it bisects.
+                // searchsorted(cdf, u, side='right') for both walks.  While scanning forward from the guide start each
+                // iteration looks at two consecutive entries and their destinations (one 16-byte and one 8-byte load
+                // per lane, issued together so the dependent chain stays one gather per iteration; fetching the
+                // destination after the search had settled measured 6 % slower); after LIN_PROBES entries it bisects.
                 int32_t nA = -1, nB = -1;
                 while (true) {
                     const bool a_ = lA < hA, b_ = lB < hB;
@@ -176,20 +200,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                     const bool linA = nA_ < LIN_PROBES, linB = nB_ < LIN_PROBES;
                     const eidx_t mA = linA ? lA : lA + ((hA - lA) >> 1);
                     const eidx_t mB = linB ? lB : lB + ((hB - lB) >> 1);
-                    const bool a2 = a_ && linA && (mA + 1 < hA), b2 = b_ && linB && (mB + 1 < hB);
-                    const double cA0 = a_ ? edge_cdf(a.cdf, a.packed, mA) : 0.0;
-                    const double cB0 = b_ ? edge_cdf(a.cdf, a.packed, mB) : 0.0;
-                    const double cA1 = a2 ? edge_cdf(a.cdf, a.packed, mA + 1) : 2.0;
-                    const double cB1 = b2 ? edge_cdf(a.cdf, a.packed, mB + 1) : 2.0;
-                    const int32_t kA0 = (a_ && linA) ? edge_col(a.col, a.packed, mA) : -1;
-                    const int32_t kB0 = (b_ && linB) ? edge_col(a.col, a.packed, mB) : -1;
-                    const int32_t kA1 = a2 ? edge_col(a.col, a.packed, mA + 1) : -1;
-                    const int32_t kB1 = b2 ? edge_col(a.col, a.packed, mB + 1) : -1;
+                    const bool a2 = a_ && linA && (mA + 1 < hA) && cdf_pair_ok(a.packed, mA);
+                    const bool b2 = b_ && linB && (mB + 1 < hB) && cdf_pair_ok(a.packed, mB);
+                    double cA0 = 0.0, cA1 = 2.0, cB0 = 0.0, cB1 = 2.0;
+                    int32_t kA0 = -1, kA1 = -1, kB0 = -1, kB1 = -1;
+                    if (a2) { edge_cdf_pair(a.cdf, a.packed, mA, cA0, cA1); edge_col_pair(a.col, a.packed, mA, kA0, kA1); }
+                    else if (a_) { cA0 = edge_cdf(a.cdf, a.packed, mA); if (linA) kA0 = edge_col(a.col, a.packed, mA); }
+                    if (b2) { edge_cdf_pair(a.cdf, a.packed, mB, cB0, cB1); edge_col_pair(a.col, a.packed, mB, kB0, kB1); }
+                    else if (b_) { cB0 = edge_cdf(a.cdf, a.packed, mB); if (linB) kB0 = edge_col(a.col, a.packed, mB); }
                     if (a_) {
                         if (linA) {
                             if (cA0 > uA) { hA = mA; lA = mA; nA = kA0; }
-                            else if (cA1 > uA) { lA = mA + 1; hA = lA; nA = kA1; }   // only reachable when a2
-                            else { lA = mA + 2; nA_ += 2; }
+                            else if (a2 && cA1 > uA) { lA = mA + 1; hA = lA; nA = kA1; }
+                            else { lA = mA + (a2 ? 2 : 1); nA_ += a2 ? 2 : 1; }
                         } else {
                             if (cA0 <= uA) lA = mA + 1; else hA = mA;
                         }
@@ -197,8 +220,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                     if (b_) {
                         if (linB) {
                             if (cB0 > uB) { hB = mB; lB = mB; nB = kB0; }
-                            else if (cB1 > uB) { lB = mB + 1; hB = lB; nB = kB1; }
-                            else { lB = mB + 2; nB_ += 2; }
+                            else if (b2 && cB1 > uB) { lB = mB + 1; hB = lB; nB = kB1; }
+                            else { lB = mB + (b2 ? 2 : 1); nB_ += b2 ? 2 : 1; }
                         } else {
                             if (cB0 <= uB) lB = mB + 1; else hB = mB;
                         }
