@@ -34,7 +34,7 @@ extern "C" {
 #define PS_EUNSUPPORTED (-4)
 
 #define PS_RNG_STREAM 0     /* uniforms[] holds the numpy legacy MT19937 stream */
-#define PS_RNG_PHILOX 1     /* Philox4x32-10, counter (node, walk, step, call)  */
+#define PS_RNG_PHILOX 1     /* Philox4x32-10, counter (node, walk, step/2, call): one block = two steps  */
 
 typedef void *ps_stream_t;
 
@@ -81,7 +81,7 @@ int ps_graph_stats(const int64_t *rowptr, const int32_t *col, int64_t E, int64_t
  * visit counts over walk[1:], top-T by (count desc, first-visit order), one wave per start node.
  * rng_mode PS_RNG_STREAM: step (walk w, step s) of start i reads uniforms[uoff[i] + w*L + s]
  *   (uoff int64[B]; the numpy call order on a graph without reachable sinks).
- * rng_mode PS_RNG_PHILOX: uniforms/uoff ignored; u = philox(seed; node, w, s, call).
+ * rng_mode PS_RNG_PHILOX: uniforms/uoff ignored; u = philox(seed; node, w, s/2, call) words (0,1) for even s, (2,3) for odd s.
  * Out: ids int32[B,T] (-1 pad), counts int32[B,T] (0 pad), nvalid int32[B].
  * The reference's weights are counts[i,j] / sum_j counts[i,:nvalid[i]] (:113-115).
  * nodeinfo/guide (both or neither; from ps_guide_build) select the bucket-table lookup; NULL = plain
@@ -95,7 +95,7 @@ int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf,
 
 /* _single_walk (utils/random_walk.py:52-83), batched: one walk of L steps per start node, one lane
  * per walk.  paths int32[B,L]: the visited nodes after the start (-1 once the walk hit a sink).
- * PS_RNG_STREAM: walk i, step s reads uniforms[uoff[i] + s]; PS_RNG_PHILOX: philox(seed; node, w, s, call)
+ * PS_RNG_STREAM: walk i, step s reads uniforms[uoff[i] + s]; PS_RNG_PHILOX: philox(seed; node, w, s/2, call)
  * with walk id w = i (walk_mod == 0) or i % walk_mod (replays walk w of ps_walk_sample when the start
  * nodes are repeated W = walk_mod times). */
 int ps_walk_paths(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,

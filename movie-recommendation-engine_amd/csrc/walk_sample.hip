@@ -34,10 +34,14 @@ struct WalkArgs {
     int32_t *counts;
     int32_t *nvalid;
     int hs_log2;
+    int stage_blocks;   // start rows of at most this many 128-byte blocks are searched in LDS
+    int region_words;   // LDS words shared by the staged row (walk phase) and the hash table (count phase)
 };
 
-__device__ __forceinline__ double philox_uniform(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
-                                                 uint32_t c2, uint32_t c3) {
+// One Philox4x32-10 block = the uniforms of two consecutive steps of a walk: counter (node, walk, step / 2, call);
+// words (0, 1) -> even step, (2, 3) -> odd step.
+__device__ __forceinline__ void philox_uniform2(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
+                                                uint32_t c3, double &u_even, double &u_odd) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -50,7 +54,8 @@ __device__ __forceinline__ double philox_uniform(uint32_t k0, uint32_t k1, uint3
         k1 += 0xBB67AE85u;
     }
     // genrand_res53 combination of two 32-bit words
-    return ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) * (1.0 / 9007199254740992.0);
+    u_even = ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) * (1.0 / 9007199254740992.0);
+    u_odd = ((double)(c2 >> 5) * 67108864.0 + (double)(c3 >> 6)) * (1.0 / 9007199254740992.0);
 }
 
 __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
@@ -107,6 +112,113 @@ __device__ __forceinline__ void edge_col_pair(const int32_t *col, const unsigned
     k1 = v.k1;
 }
 
+// The same accessors over a copy of the start row's packed blocks in LDS (block b0 is at `base`): step 0 of every
+// walk of a wave reads the SAME row, so rows of up to `stage_blocks` blocks are streamed into LDS once (coalesced
+// 16 B per lane) and searched there instead of through ~5 dependent gathers per walk.
+struct GlobalEdges {
+    const double *cdf;
+    const int32_t *col;
+    const int32_t *guide;
+    const unsigned char *packed;
+    __device__ __forceinline__ bool has_guide() const { return guide || packed; }
+    __device__ __forceinline__ bool pair_ok(eidx_t e) const { return cdf_pair_ok(packed, e); }
+    __device__ __forceinline__ double c(eidx_t e) const { return edge_cdf(cdf, packed, e); }
+    __device__ __forceinline__ int32_t k(eidx_t e) const { return edge_col(col, packed, e); }
+    __device__ __forceinline__ void c2(eidx_t e, double &c0, double &c1) const { edge_cdf_pair(cdf, packed, e, c0, c1); }
+    __device__ __forceinline__ void k2(eidx_t e, int32_t &k0, int32_t &k1) const { edge_col_pair(col, packed, e, k0, k1); }
+    __device__ __forceinline__ int32_t g(eidx_t e) const {
+        return packed ? reinterpret_cast<const int32_t *>(packed + (size_t)(e >> 3) * 128 + 96)[e & 7] : guide[e];
+    }
+};
+
+struct LdsEdges {
+    const unsigned char *base;   // LDS
+    eidx_t b0;
+    __device__ __forceinline__ const unsigned char *blk(eidx_t e) const { return base + ((e >> 3) - b0) * 128; }
+    __device__ __forceinline__ bool has_guide() const { return true; }
+    __device__ __forceinline__ bool pair_ok(eidx_t e) const { return (e & 7) < 7; }
+    __device__ __forceinline__ double c(eidx_t e) const { return reinterpret_cast<const double *>(blk(e))[e & 7]; }
+    __device__ __forceinline__ int32_t k(eidx_t e) const { return reinterpret_cast<const int32_t *>(blk(e) + 64)[e & 7]; }
+    __device__ __forceinline__ void c2(eidx_t e, double &c0, double &c1) const {
+        const double *p = reinterpret_cast<const double *>(blk(e)) + (e & 7);
+        c0 = p[0];
+        c1 = p[1];
+    }
+    __device__ __forceinline__ void k2(eidx_t e, int32_t &k0, int32_t &k1) const {
+        const int32_t *p = reinterpret_cast<const int32_t *>(blk(e) + 64) + (e & 7);
+        k0 = p[0];
+        k1 = p[1];
+    }
+    __device__ __forceinline__ int32_t g(eidx_t e) const { return reinterpret_cast<const int32_t *>(blk(e) + 96)[e & 7]; }
+};
+
+// searchsorted(cdf[lo:hi], u, side='right') for two independent walks in lockstep -> destination ids nA, nB.
+// With a guide table the search starts at bucket floor(u * deg) (guide = #{cdf <= (j/deg)(1-2^-50)} <= answer) and scans
+// forward: each iteration looks at two consecutive entries and their destinations (one 16-byte and one 8-byte load per
+// lane, issued together so the dependent chain stays one gather per iteration; fetching the destination after the search
+// had settled measured 6 % slower); after LIN_PROBES entries, or without a guide, it bisects.
+template <class Acc>
+__device__ __forceinline__ void search_two(const Acc &acc, bool aliveA, eidx_t loA, eidx_t hiA, double uA, bool aliveB,
+                                           eidx_t loB, eidx_t hiB, double uB, int32_t &nA, int32_t &nB) {
+    eidx_t lA = loA, hA = loA, lB = loB, hB = loB;
+    int nA_ = LIN_PROBES, nB_ = LIN_PROBES;
+    if (acc.has_guide()) {
+        if (aliveA) {
+            const uint32_t deg = (uint32_t)(hiA - loA);
+            uint32_t j = (uint32_t)(uA * (double)deg);
+            if (j >= deg) j = deg - 1;
+            lA = loA + (eidx_t)acc.g(loA + j);
+            nA_ = 0;
+        }
+        if (aliveB) {
+            const uint32_t deg = (uint32_t)(hiB - loB);
+            uint32_t j = (uint32_t)(uB * (double)deg);
+            if (j >= deg) j = deg - 1;
+            lB = loB + (eidx_t)acc.g(loB + j);
+            nB_ = 0;
+        }
+    }
+    if (aliveA) hA = hiA;
+    if (aliveB) hB = hiB;
+    nA = -1;
+    nB = -1;
+    while (true) {
+        const bool a_ = lA < hA, b_ = lB < hB;
+        if (!a_ && !b_) break;
+        const bool linA = nA_ < LIN_PROBES, linB = nB_ < LIN_PROBES;
+        const eidx_t mA = linA ? lA : lA + ((hA - lA) >> 1);
+        const eidx_t mB = linB ? lB : lB + ((hB - lB) >> 1);
+        const bool a2 = a_ && linA && (mA + 1 < hA) && acc.pair_ok(mA);
+        const bool b2 = b_ && linB && (mB + 1 < hB) && acc.pair_ok(mB);
+        double cA0 = 0.0, cA1 = 2.0, cB0 = 0.0, cB1 = 2.0;
+        int32_t kA0 = -1, kA1 = -1, kB0 = -1, kB1 = -1;
+        if (a2) { acc.c2(mA, cA0, cA1); acc.k2(mA, kA0, kA1); }
+        else if (a_) { cA0 = acc.c(mA); if (linA) kA0 = acc.k(mA); }
+        if (b2) { acc.c2(mB, cB0, cB1); acc.k2(mB, kB0, kB1); }
+        else if (b_) { cB0 = acc.c(mB); if (linB) kB0 = acc.k(mB); }
+        if (a_) {
+            if (linA) {
+                if (cA0 > uA) { hA = mA; lA = mA; nA = kA0; }
+                else if (a2 && cA1 > uA) { lA = mA + 1; hA = lA; nA = kA1; }
+                else { lA = mA + (a2 ? 2 : 1); nA_ += a2 ? 2 : 1; }
+            } else {
+                if (cA0 <= uA) lA = mA + 1; else hA = mA;
+            }
+        }
+        if (b_) {
+            if (linB) {
+                if (cB0 > uB) { hB = mB; lB = mB; nB = kB0; }
+                else if (b2 && cB1 > uB) { lB = mB + 1; hB = lB; nB = kB1; }
+                else { lB = mB + (b2 ? 2 : 1); nB_ += b2 ? 2 : 1; }
+            } else {
+                if (cB0 <= uB) lB = mB + 1; else hB = mB;
+            }
+        }
+    }
+    if (aliveA) { if (lA >= hiA) lA = hiA - 1; if (nA < 0) nA = acc.k(lA); }
+    if (aliveB) { if (lB >= hiB) lB = hiB - 1; if (nB < 0) nB = acc.k(lB); }
+}
+
 // Start state of searchsorted(cdf[lo:hi], u, 'right'): with a guide table the search starts at the bucket
 // floor(u * deg) (guide = #{cdf <= (j-1)/deg} <= answer) and first scans forward; `n` counts probes.
 __device__ __forceinline__ void search_init(const int32_t *guide, const unsigned char *packed, eidx_t lo, eidx_t hi,
@@ -133,12 +245,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
     const int wv = threadIdx.x >> 6;
     const int HS = 1 << a.hs_log2;
     const int P = a.W * a.L;
-    const int per_wave = NP * 64 + 3 * HS + BITMAP_WORDS;
+    const int per_wave = NP * 64 + a.region_words + BITMAP_WORDS;
     int32_t *posb = smem + wv * per_wave;
     int32_t *hkey = posb + NP * 64;
     int32_t *hcnt = hkey + HS;
     int32_t *hfirst = hcnt + HS;
-    uint32_t *bitmap = reinterpret_cast<uint32_t *>(hfirst + HS);
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(hkey + a.region_words);
+    const GlobalEdges grow{a.cdf, a.col, a.guide, a.packed};
     const int nbw = (P >> 5) + 1;
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
 
@@ -161,6 +274,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         // ---------------- walk phase --------------------------------------------------
 #pragma unroll
         for (int j = 0; j < NP; ++j) posb[j * 64 + lane] = -1;
+        // the start row's packed blocks -> LDS (over the hash-table area, which is initialised after the walks)
+        const eidx_t b0 = lo0 >> 3, nblk = ((hi0 - 1) >> 3) - b0 + 1;
+        const bool staged = a.packed != nullptr && nblk <= (eidx_t)a.stage_blocks;
+        if (staged) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.packed + (size_t)b0 * 128);
+            uint4 *dst = reinterpret_cast<uint4 *>(hkey);
+            for (int q = lane; q < (int)nblk * 8; q += 64) dst[q] = src[q];
+        }
+        const LdsEdges lrow{reinterpret_cast<const unsigned char *>(hkey), b0};
         ps_wave_lds_sync();
         // two walks per lane (w and w + 64) advance in lockstep: their CDF probes are independent, so
         // every iteration of the search loop keeps two loads in flight per lane.
@@ -169,6 +291,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             const bool actA = wA < a.W, actB = wB < a.W;
             bool aliveA = actA, aliveB = actB;
             int32_t curA = (int32_t)s, curB = (int32_t)s;
+            double uA1 = 2.0, uB1 = 2.0;
             for (int st = 0; st < a.L; ++st) {
                 eidx_t loA = lo0, hiA = hi0, loB = lo0, hiB = hi0;
                 if (st > 0) {
@@ -181,54 +304,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                 if (a.rng_mode == PS_RNG_STREAM) {
                     if (aliveA) uA = a.uniforms[ubase + (int64_t)wA * a.L + st];
                     if (aliveB) uB = a.uniforms[ubase + (int64_t)wB * a.L + st];
+                } else if ((st & 1) == 0) {
+                    philox_uniform2(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wA, (uint32_t)(st >> 1), a.call, uA, uA1);
+                    philox_uniform2(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wB, (uint32_t)(st >> 1), a.call, uB, uB1);
                 } else {
-                    if (aliveA) uA = philox_uniform(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wA, (uint32_t)st, a.call);
-                    if (aliveB) uB = philox_uniform(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wB, (uint32_t)st, a.call);
+                    uA = uA1;
+                    uB = uB1;
                 }
-                eidx_t lA = loA, hA = loA, lB = loB, hB = loB;
-                int nA_ = 0, nB_ = 0;
-                if (aliveA) { search_init(a.guide, a.packed, loA, hiA, uA, lA, nA_); hA = hiA; }
-                if (aliveB) { search_init(a.guide, a.packed, loB, hiB, uB, lB, nB_); hB = hiB; }
-                // searchsorted(cdf, u, side='right') for both walks.  While scanning forward from the guide start each
-                // iteration looks at two consecutive entries and their destinations (one 16-byte and one 8-byte load
-                // per lane, issued together so the dependent chain stays one gather per iteration; fetching the
-                // destination after the search had settled measured 6 % slower); after LIN_PROBES entries it bisects.
                 int32_t nA = -1, nB = -1;
-                while (true) {
-                    const bool a_ = lA < hA, b_ = lB < hB;
-                    if (!a_ && !b_) break;
-                    const bool linA = nA_ < LIN_PROBES, linB = nB_ < LIN_PROBES;
-                    const eidx_t mA = linA ? lA : lA + ((hA - lA) >> 1);
-                    const eidx_t mB = linB ? lB : lB + ((hB - lB) >> 1);
-                    const bool a2 = a_ && linA && (mA + 1 < hA) && cdf_pair_ok(a.packed, mA);
-                    const bool b2 = b_ && linB && (mB + 1 < hB) && cdf_pair_ok(a.packed, mB);
-                    double cA0 = 0.0, cA1 = 2.0, cB0 = 0.0, cB1 = 2.0;
-                    int32_t kA0 = -1, kA1 = -1, kB0 = -1, kB1 = -1;
-                    if (a2) { edge_cdf_pair(a.cdf, a.packed, mA, cA0, cA1); edge_col_pair(a.col, a.packed, mA, kA0, kA1); }
-                    else if (a_) { cA0 = edge_cdf(a.cdf, a.packed, mA); if (linA) kA0 = edge_col(a.col, a.packed, mA); }
-                    if (b2) { edge_cdf_pair(a.cdf, a.packed, mB, cB0, cB1); edge_col_pair(a.col, a.packed, mB, kB0, kB1); }
-                    else if (b_) { cB0 = edge_cdf(a.cdf, a.packed, mB); if (linB) kB0 = edge_col(a.col, a.packed, mB); }
-                    if (a_) {
-                        if (linA) {
-                            if (cA0 > uA) { hA = mA; lA = mA; nA = kA0; }
-                            else if (a2 && cA1 > uA) { lA = mA + 1; hA = lA; nA = kA1; }
-                            else { lA = mA + (a2 ? 2 : 1); nA_ += a2 ? 2 : 1; }
-                        } else {
-                            if (cA0 <= uA) lA = mA + 1; else hA = mA;
-                        }
-                    }
-                    if (b_) {
-                        if (linB) {
-                            if (cB0 > uB) { hB = mB; lB = mB; nB = kB0; }
-                            else if (b2 && cB1 > uB) { lB = mB + 1; hB = lB; nB = kB1; }
-                            else { lB = mB + (b2 ? 2 : 1); nB_ += b2 ? 2 : 1; }
-                        } else {
-                            if (cB0 <= uB) lB = mB + 1; else hB = mB;
-                        }
-                    }
-                }
-                if (aliveA) { if (lA >= hiA) lA = hiA - 1; if (nA < 0) nA = edge_col(a.col, a.packed, lA); curA = nA; }
-                if (aliveB) { if (lB >= hiB) lB = hiB - 1; if (nB < 0) nB = edge_col(a.col, a.packed, lB); curB = nB; }
+                if (staged && st == 0) search_two(lrow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
+                else search_two(grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
+                if (aliveA) curA = nA;
+                if (aliveB) curB = nB;
                 if (actA) posb[wA * a.L + st] = nA;
                 if (actB) posb[wB * a.L + st] = nB;
             }
@@ -310,9 +397,13 @@ __global__ void walk_paths_kernel(const int64_t *rowptr, const int32_t *col, con
                 if (hi == lo) {
                     alive = false;
                 } else {
-                    double u;
-                    if (rng_mode == PS_RNG_STREAM) u = uniforms[ubase + st];
-                    else u = philox_uniform(k0, k1, (uint32_t)s, (uint32_t)(walk_mod > 0 ? i % walk_mod : i), (uint32_t)st, call);
+                    double u, u_odd;
+                    if (rng_mode == PS_RNG_STREAM) {
+                        u = uniforms[ubase + st];
+                    } else {
+                        philox_uniform2(k0, k1, (uint32_t)s, (uint32_t)(walk_mod > 0 ? i % walk_mod : i), (uint32_t)(st >> 1), call, u, u_odd);
+                        if (st & 1) u = u_odd;
+                    }
                     eidx_t l, h = hi;
                     int n;
                     search_init(guide, nullptr, lo, hi, u, l, n);
@@ -404,8 +495,16 @@ extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const d
     int hs_log2 = 6;
     while ((1 << hs_log2) * 4 < 5 * P) ++hs_log2;      // table >= 1.25 P slots (load factor <= 0.8)
     WalkArgs a{rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff,
-               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2};
-    const size_t lds = (size_t)WAVES_PER_BLOCK * (np * 64 + 3 * (1 << hs_log2) + BITMAP_WORDS) * sizeof(int32_t);
+               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0};
+    // LDS budget: the kernel holds 24 waves per CU by registers; 160 KB / 24 leaves ~6.6 KB per wave, and whatever
+    // the hash table does not need of that lets longer start rows be staged.
+    const int hash_words = 3 * (1 << hs_log2);
+    int region_words = (6656 / 4) - np * 64 - BITMAP_WORDS;
+    if (region_words < hash_words) region_words = hash_words;
+    region_words &= ~31;                                    // whole 128-byte blocks
+    a.region_words = region_words;
+    a.stage_blocks = packed ? region_words / 32 : 0;
+    const size_t lds = (size_t)WAVES_PER_BLOCK * (np * 64 + region_words + BITMAP_WORDS) * sizeof(int32_t);
     int64_t grid = ps_cdiv(B, WAVES_PER_BLOCK);
     if (grid > (int64_t)1 << 30) grid = (int64_t)1 << 30;
     hipStream_t st = ps_stream(stream);

@@ -118,9 +118,11 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 static inline double philox_uniform(uint64_t seed, uint32_t call, uint32_t node, uint32_t walk, uint32_t step) {
-    uint32_t c[4] = {node, walk, step, call};
+    /* one block serves two consecutive steps: words 0,1 for the even step, 2,3 for the odd one */
+    uint32_t c[4] = {node, walk, step >> 1, call};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) / 9007199254740992.0;
+    const uint32_t a = (step & 1) ? c[2] : c[0], b = (step & 1) ? c[3] : c[1];
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
 /* searchsorted(cdf[lo:hi], u, side='right') */

@@ -15,6 +15,10 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t seed
             if (OP == 2) { asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(x)); }
             if (OP == 3) { asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "v"(x)); }
             if (OP == 4) { asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "v"(x)); }
+            if (OP == 5) { asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(a[i]) : "v"(x)); }
+            if (OP == 6) { asm volatile("v_mul_hi_u32 %0, %1, %0" : "+v"(a[i]) : "v"(x)); }
+            if (OP == 7) { uint64_t r; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a[i]), "v"(x) : "vcc"); a[i] = (uint32_t)r ^ (uint32_t)(r >> 32); }
+            if (OP == 8) { asm volatile("v_mul_u32_u24 %0, %1, %0" : "+v"(a[i]) : "v"(x)); }
         }
     }
     uint32_t s = 0;
@@ -40,6 +44,10 @@ int main() {
     run<2>("v_bcnt_u32_b32 (asm)", 1);
     run<3>("v_xor_b32 (asm)", 1);
     run<4>("v_add_u32 (asm)", 1);
+    run<5>("v_mul_lo_u32 (asm)", 1);
+    run<6>("v_mul_hi_u32 (asm)", 1);
+    run<7>("v_mad_u64_u32 + xor", 2);
+    run<8>("v_mul_u32_u24 (asm)", 1);
     run<0>("xor+bcnt (C)", 2);
     run<1>("xor+shift+add (C)", 3);
     return 0;
