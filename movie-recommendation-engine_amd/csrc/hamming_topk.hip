@@ -16,25 +16,29 @@ namespace {
 // the tile; the query code is wave-uniform, so it comes in through scalar loads (the next query's code is
 // requested before the current one is consumed) and costs no vector registers or LDS.  Per 32-bit word
 // and 64 (query, item) pairs: v_xor + v_bcnt accumulate.
-// Top-k: lane qi of `tau` holds query qi's admission bound (its current k-th best key, distance << 32 |
-// local id); a ballot of "key < tau" is almost always empty.  Otherwise the wave-uniform rare path pulls
-// that query's sorted list out of LDS (lane p = p-th best), inserts the candidates in lane (= id) order --
-// position by ballot + popcount, shift by one lane -- and stores it back.  No divergence, no atomics; ids
-// ascend during the sweep, so "key < current worst" is exactly faiss' strict-less admission.
+// Top-k: a candidate is ONE 32-bit key, distance << SHIFT | slice-local id (the host cuts the table so that a
+// slice has at most 2^SHIFT items), so "better" is a single unsigned compare.  Lane qi of `tau` holds query
+// qi's admission bound (its current k-th best key); a ballot of "distance < bound's distance" is almost always
+// empty.  Otherwise the wave-uniform rare path pulls that query's sorted list out of LDS (lane p = p-th best),
+// inserts the candidates in lane (= id) order -- position by ballot + popcount, shift by one lane -- and
+// stores it back.  No divergence, no atomics; ids ascend during the sweep, so "key < current worst" is exactly
+// faiss' strict-less admission.
 // lane p receives lane p-1's value (lane 0 keeps its own): DPP wave_shr:1, no LDS crossbar round trip
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+constexpr uint32_t EMPTY_KEY = 0xffffffffu;
+
 template <int WORDS, int G>
 __global__ __launch_bounds__(256) void hamming_scan_kernel(const uint32_t *__restrict__ q, int64_t nq,
                                                            const uint32_t *__restrict__ codes, int64_t N, int k,
-                                                           int kcap, int QT, int splits, int64_t id_offset,
+                                                           int kcap, int QT, int splits, int shift, int64_t id_offset,
                                                            int32_t *__restrict__ odist, int64_t *__restrict__ oids) {
-    extern __shared__ uint64_t lists_all[];                           // [4 waves][QT][kcap]
+    extern __shared__ uint32_t lists_all[];                           // [4 waves][QT][kcap]
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    uint64_t *L = lists_all + (size_t)wv * QT * kcap;
+    uint32_t *L = lists_all + (size_t)wv * QT * kcap;
     const int64_t gw = (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
     const int64_t ntiles = (nq + QT - 1) / QT;
     if (gw >= ntiles * splits) return;
@@ -47,32 +51,29 @@ __global__ __launch_bounds__(256) void hamming_scan_kernel(const uint32_t *__res
     const int nqt = (int)((nq - q0) < QT ? (nq - q0) : QT);
     const bool vec_ok = (WORDS % 4 == 0) && (reinterpret_cast<size_t>(codes) % 16 == 0);
 
-    for (int i = lane; i < QT * kcap; i += 64) L[i] = 0xffffffffffffffffull;
+    for (int i = lane; i < QT * kcap; i += 64) L[i] = EMPTY_KEY;
     ps_wave_lds_sync();
-    uint32_t tau_lo = 0xffffffffu, tau_hi = 0xffffffffu;             // lane qi: admission bound of query qi
+    uint32_t tau = EMPTY_KEY;                                          // lane qi: admission bound of query qi
 
     for (int64_t g = j0; g < j1; g += 64 * G) {
         uint32_t it[G][WORDS];
-        uint32_t klo[G];
-        bool valid[G];
-        uint64_t vmask[G];
+        uint32_t klo[G];                                              // slice-local id, all ones when out of range
 #pragma unroll
         for (int gg = 0; gg < G; ++gg) {
             const int64_t j = g + gg * 64 + lane;
-            valid[gg] = j < j1;
-            vmask[gg] = __ballot(valid[gg]);
-            klo[gg] = (uint32_t)(j - j0);
+            const bool valid = j < j1;
+            klo[gg] = valid ? (uint32_t)(j - j0) : EMPTY_KEY;
             if (vec_ok) {
 #pragma unroll
                 for (int w = 0; w < WORDS; w += 4) {
                     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (valid[gg]) v = *reinterpret_cast<const uint4 *>(codes + j * WORDS + w);
+                    if (valid) v = *reinterpret_cast<const uint4 *>(codes + j * WORDS + w);
                     it[gg][w] = v.x; it[gg][w + 1 < WORDS ? w + 1 : w] = v.y;
                     it[gg][w + 2 < WORDS ? w + 2 : w] = v.z; it[gg][w + 3 < WORDS ? w + 3 : w] = v.w;
                 }
             } else {
 #pragma unroll
-                for (int w = 0; w < WORDS; ++w) it[gg][w] = valid[gg] ? codes[j * WORDS + w] : 0u;
+                for (int w = 0; w < WORDS; ++w) it[gg][w] = valid ? codes[j * WORDS + w] : 0u;
             }
         }
         uint32_t cur[WORDS];
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256) void hamming_scan_kernel(const uint32_t *__res
             uint32_t nxt[WORDS];
 #pragma unroll
             for (int w = 0; w < WORDS; ++w) nxt[w] = q[(q0 + qn) * WORDS + w];   // in flight during the compares
-            uint32_t thi = __builtin_amdgcn_readlane(tau_hi, qi);
+            uint32_t tk = __builtin_amdgcn_readlane(tau, qi);
+            const uint32_t thi = tk >> shift;
             uint32_t d[G];
             uint64_t many = 0ull;
 #pragma unroll
@@ -94,47 +96,44 @@ __global__ __launch_bounds__(256) void hamming_scan_kernel(const uint32_t *__res
                 d[gg] = acc;
                 // ids ascend during the sweep: an item that ties the list's worst distance has a larger id and
                 // can never be admitted, so "distance < bound.distance" is the exact fast-path test
-                many |= __ballot(acc < thi) & vmask[gg];
+                many |= __ballot(acc < thi);
             }
             if (many != 0ull) {                                        // rare, wave-uniform
-                uint32_t tlo = __builtin_amdgcn_readlane(tau_lo, qi);
-                uint64_t lk = (lane < kcap) ? L[qi * kcap + lane] : 0xffffffffffffffffull;
-                uint32_t llo = (uint32_t)lk, lhi = (uint32_t)(lk >> 32);
+                uint32_t lk = (lane < kcap) ? L[qi * kcap + lane] : EMPTY_KEY;
 #pragma unroll
                 for (int gg = 0; gg < G; ++gg) {
                     // candidates of this group against the CURRENT bound (it tightens with every insertion,
                     // so stale candidates drop out of the ballot instead of being visited one by one)
-                    uint64_t mask = __ballot(valid[gg] && (d[gg] < thi || (d[gg] == thi && klo[gg] < tlo)));
+                    const uint32_t key = (d[gg] << shift) | klo[gg];      // out-of-range lanes: all ones = EMPTY_KEY
+                    uint64_t mask = __ballot(key < tk);
                     while (mask != 0ull) {
                         const int b = __builtin_ctzll(mask);
-                        const uint32_t clo = __builtin_amdgcn_readlane(klo[gg], b);
-                        const uint32_t chi = __builtin_amdgcn_readlane(d[gg], b);
-                        const uint64_t lt = __ballot(lhi < chi || (lhi == chi && llo < clo));
-                        const int pos = __popcll(lt);                  // the list is sorted: lt is a prefix
-                        const uint32_t slo = wave_shr1(llo), shi = wave_shr1(lhi);
-                        if (lane == pos) { llo = clo; lhi = chi; }
-                        else if (lane > pos) { llo = slo; lhi = shi; }
-                        tlo = __builtin_amdgcn_readlane(llo, k - 1);
-                        thi = __builtin_amdgcn_readlane(lhi, k - 1);
+                        const uint32_t c = __builtin_amdgcn_readlane(key, b);
+                        const int pos = __popcll(__ballot(lk < c));     // the list is sorted: a prefix
+                        const uint32_t sh = wave_shr1(lk);
+                        lk = (lane > pos) ? sh : lk;
+                        lk = (lane == pos) ? c : lk;
+                        tk = __builtin_amdgcn_readlane(lk, k - 1);
                         const uint64_t above = (b == 63) ? 0ull : (~0ull << (b + 1));
-                        mask = __ballot(valid[gg] && (d[gg] < thi || (d[gg] == thi && klo[gg] < tlo))) & above;
+                        mask = __ballot(key < tk) & above;
                     }
                 }
-                if (lane < kcap) L[qi * kcap + lane] = ((uint64_t)lhi << 32) | llo;
-                if (lane == qi) { tau_lo = tlo; tau_hi = thi; }
+                if (lane < kcap) L[qi * kcap + lane] = lk;
+                if (lane == qi) tau = tk;
             }
 #pragma unroll
             for (int w = 0; w < WORDS; ++w) cur[w] = nxt[w];
         }
     }
     ps_wave_lds_sync();
+    const uint32_t idmask = (1u << shift) - 1u;
     for (int i = lane; i < nqt * k; i += 64) {
         const int qi = i / k, p = i - qi * k;
-        const uint64_t key = L[qi * kcap + p];
+        const uint32_t key = L[qi * kcap + p];
         const int64_t o = ((int64_t)split * nq + q0 + qi) * k + p;
-        const bool has = key != 0xffffffffffffffffull;
-        odist[o] = has ? (int32_t)(key >> 32) : 0x7fffffff;
-        oids[o] = has ? (int64_t)(uint32_t)key + j0 + id_offset : -1;
+        const bool has = key != EMPTY_KEY;
+        odist[o] = has ? (int32_t)(key >> shift) : 0x7fffffff;
+        oids[o] = has ? (int64_t)(key & idmask) + j0 + id_offset : -1;
     }
 }
 
@@ -187,6 +186,13 @@ int pick_tile(int64_t nq, int64_t table_bytes) {
     return table_bytes >= ((int64_t)256 << 20) ? 32 : 4;
 }
 
+// key = distance << shift | slice-local id: distances of cs-byte codes need log2(8 cs) + 1 bits
+int key_shift(int cs) {
+    int dbits = 1;
+    while ((1 << (dbits - 1)) < cs * 8) ++dbits;
+    return 32 - dbits;
+}
+
 int pick_splits(int64_t nq, int64_t N, int cs) {
     const int qt = pick_tile(nq, N * cs);
     const int64_t tiles = (nq + qt - 1) / qt;
@@ -194,6 +200,9 @@ int pick_splits(int64_t nq, int64_t N, int cs) {
     if (s < 1) s = 1;
     if (s > 1024) s = 1024;
     while (s > 1 && N / s < 1024) s >>= 1;           // keep slices worth sweeping
+    const int64_t cap = (int64_t)1 << key_shift(cs);  // a slice's local ids must fit under the distance bits
+    const int64_t smin = (N + cap - 1) / cap;
+    if (s < smin) s = smin;
     return (int)s;
 }
 
@@ -245,12 +254,13 @@ extern "C" int ps_hamming_topk(const uint8_t *qcodes, int64_t nq, const uint8_t 
     const unsigned grid = (unsigned)ps_cdiv(waves, 4);
     int kcap = 16;
     while (kcap < k) kcap <<= 1;
-    const size_t lds = (size_t)4 * QUERY_TILE * kcap * sizeof(uint64_t);
+    const size_t lds = (size_t)4 * QUERY_TILE * kcap * sizeof(uint32_t);
+    const int shift = key_shift(cs);
     const uint32_t *q32 = reinterpret_cast<const uint32_t *>(qcodes);
     const uint32_t *c32 = reinterpret_cast<const uint32_t *>(codes);
 #define PS_LAUNCH_SCAN(WORDS_)                                                                                  \
     hipLaunchKernelGGL((hamming_scan_kernel<WORDS_, (WORDS_ >= 32 ? 2 : 4)>), dim3(grid), dim3(256), lds, st, q32, nq, \
-                       c32, N, k, kcap, QUERY_TILE, s, id_offset, cd, ci)
+                       c32, N, k, kcap, QUERY_TILE, s, shift, id_offset, cd, ci)
     switch (words) {
         case 1: PS_LAUNCH_SCAN(1); break;
         case 2: PS_LAUNCH_SCAN(2); break;
