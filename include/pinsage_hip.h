@@ -70,6 +70,14 @@ int ps_guide_build(const int64_t *rowptr, const double *cdf, int64_t V, uint32_t
 int ps_pack_edges(const int32_t *col, const double *cdf, const int32_t *guide, int64_t E, void *packed,
                   ps_stream_t stream);
 
+/* Bucket records: one 64-byte record per bucket e = lo_v + j of the guide table,
+ *   [ c0 c1 | c2 c3 | k0 k1 k2 k3 | c4 k4 - ]   ci fp64 = cdf[lo_v + guide[e] + i], ki int32 = col[same]
+ * (past the row end: ci = 2.0, ki = the row's last destination), so searchsorted(cdf_v, u, 'right') = first i with
+ * ci > u is answered from ONE 64-byte sector per walk step; a lane that needs more than five candidates repeats the
+ * search through the packed blocks.  buckets: 64 * E bytes, 64-B aligned.  Optional (4x the adjacency's memory). */
+int ps_bucket_build(const int64_t *rowptr, const int32_t *col, const double *cdf, const int32_t *guide, int64_t V,
+                    int64_t E, void *buckets, ps_stream_t stream);
+
 /* flags[0] = 1 iff some edge points at a node with out-degree 0 (a reachable sink: the
  * reference's walk then breaks early, utils/random_walk.py:68-69, and its RNG consumption
  * becomes data dependent); flags[1] = max out-degree.  flags int64[2]. */
@@ -86,12 +94,14 @@ int ps_graph_stats(const int64_t *rowptr, const int32_t *col, int64_t E, int64_t
  * The reference's weights are counts[i,j] / sum_j counts[i,:nvalid[i]] (:113-115).
  * nodeinfo/guide (both or neither; from ps_guide_build) select the bucket-table lookup; NULL = plain
  * binary search over the CDF row.  packed (from ps_pack_edges; needs nodeinfo) reads cdf/col/guide from
- * the interleaved 128-byte blocks instead of the three arrays. */
+ * the interleaved 128-byte blocks instead of the three arrays; start rows of up to ~40 blocks are searched in LDS.
+ * buckets (from ps_bucket_build; needs nodeinfo) answers every other step from one 64-byte record. */
 int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                    const int64_t *starts, int64_t B, int W, int L, int T,
                    int rng_mode, const double *uniforms, const int64_t *uoff,
                    uint64_t seed, uint32_t call, const uint32_t *nodeinfo, const int32_t *guide,
-                   const void *packed, int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream);
+                   const void *packed, const void *buckets, int32_t *ids, int32_t *counts, int32_t *nvalid,
+                   ps_stream_t stream);
 
 /* _single_walk (utils/random_walk.py:52-83), batched: one walk of L steps per start node, one lane
  * per walk.  paths int32[B,L]: the visited nodes after the start (-1 once the walk hit a sink).

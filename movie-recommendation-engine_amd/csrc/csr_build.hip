@@ -189,6 +189,34 @@ __global__ void pack_edges_kernel(const int32_t *col, const double *cdf, const i
     }
 }
 
+// 64-byte bucket records (see ps_bucket_build in pinsage_hip.h): [c0 c1 | c2 c3 | k0 k1 k2 k3 | c4 k4 -]
+__global__ __launch_bounds__(256) void bucket_build_kernel(const int64_t *rowptr, const int32_t *col, const double *cdf,
+                                                           const int32_t *guide, int64_t V, unsigned char *buckets) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t v = wave; v < V; v += nwaves) {
+        const int64_t lo = rowptr[v], hi = rowptr[v + 1];
+        for (int64_t e = lo + lane; e < hi; e += 64) {
+            const int64_t first = lo + guide[e];
+            double c[5];
+            int32_t k[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int64_t idx = first + i;
+                c[i] = idx < hi ? cdf[idx] : 2.0;                 // past the row end: always "> u", destination = last edge
+                k[i] = col[idx < hi ? idx : hi - 1];
+            }
+            unsigned char *r = buckets + (size_t)e * 64;
+            reinterpret_cast<double2 *>(r)[0] = make_double2(c[0], c[1]);
+            reinterpret_cast<double2 *>(r)[1] = make_double2(c[2], c[3]);
+            reinterpret_cast<int4 *>(r)[2] = make_int4(k[0], k[1], k[2], k[3]);
+            reinterpret_cast<double *>(r)[6] = c[4];
+            reinterpret_cast<int2 *>(r)[7] = make_int2(k[4], 0);
+        }
+    }
+}
+
 int radix_bits(int64_t V) {
     int bits = 1;
     while (((int64_t)1 << bits) < V && bits < 32) ++bits;
@@ -250,6 +278,19 @@ extern "C" int ps_guide_build(const int64_t *rowptr, const double *cdf, int64_t 
     int64_t g = ps_cdiv(V, 4);
     if (g > 256 * 16) g = 256 * 16;
     hipLaunchKernelGGL(guide_build_kernel, dim3((unsigned)g), dim3(256), 0, ps_stream(stream), rowptr, cdf, V, nodeinfo, guide);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+extern "C" int ps_bucket_build(const int64_t *rowptr, const int32_t *col, const double *cdf, const int32_t *guide,
+                               int64_t V, int64_t E, void *buckets, ps_stream_t stream) {
+    if (V < 0 || E < 0) return PS_EINVAL;
+    if (V == 0 || E == 0) return PS_OK;
+    if (!rowptr || !col || !cdf || !guide || !buckets || reinterpret_cast<size_t>(buckets) % 64 != 0) return PS_EINVAL;
+    int64_t g = ps_cdiv(V, 4);
+    if (g > 256 * 32) g = 256 * 32;
+    hipLaunchKernelGGL(bucket_build_kernel, dim3((unsigned)g), dim3(256), 0, ps_stream(stream), rowptr, col, cdf, guide, V,
+                       reinterpret_cast<unsigned char *>(buckets));
     PS_CHECK_LAUNCH();
     return PS_OK;
 }

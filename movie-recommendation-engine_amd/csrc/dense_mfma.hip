@@ -19,6 +19,7 @@
 // in registers while staging (two float4 global loads per row-group), global loads for the next
 // K step are in flight while the current one is multiplied.
 #include "ps_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -49,11 +50,11 @@ __device__ __forceinline__ void load8(const float *base, bool row_ok, int k, int
 // clamped to the last valid row; their results are never stored), so nothing branches or waits inside the
 // fetch and the loads stay in flight under the MFMAs.  The general variant predicates every element.
 template <int WM, int WN, int TM, int TN, int BK, int EPI, bool FAST>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     constexpr int GRP = BK / 8;                        // 8-k groups per row
     constexpr int LDS_STRIDE = BK + 4;                 // floats; 144 B (BK 32) / 80 B (BK 16): b128 reads conflict free
-    constexpr int A_ITEMS = (BM * GRP + 255) / 256, B_ITEMS = (BN * GRP + 255) / 256;   // (row, group) items per thread
+    constexpr int A_ITEMS = (BM * GRP + NT - 1) / NT, B_ITEMS = (BN * GRP + NT - 1) / NT;   // (row, group) items per thread
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_STRIDE + BM * WN];
     float *sA = smem, *sB = smem + BM * LDS_STRIDE, *sRed = smem + (BM + BN) * LDS_STRIDE;
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int q = 0; q < A_ITEMS; ++q) {
                 // FAST: no guards -- when the tile has fewer items than threads the surplus threads duplicate an
                 // item (identical loads, identical LDS writes)
-                const int it = FAST ? (tid + 256 * q) % (BM * GRP) : tid + 256 * q, row = it / GRP, grp = it % GRP;
+                const int it = FAST ? (tid + NT * q) % (BM * GRP) : tid + NT * q, row = it / GRP, grp = it % GRP;
                 const int64_t m = m0 + row;
                 if (FAST) {
                     {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             }
 #pragma unroll
             for (int q = 0; q < B_ITEMS; ++q) {
-                const int it = FAST ? (tid + 256 * q) % (BN * GRP) : tid + 256 * q, row = it / GRP, grp = it % GRP;
+                const int it = FAST ? (tid + NT * q) % (BN * GRP) : tid + NT * q, row = it / GRP, grp = it % GRP;
                 const int n = n0 + row;
                 if (FAST) {
                     {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         auto stash = [&]() {
 #pragma unroll
             for (int q = 0; q < A_ITEMS; ++q) {
-                const int it = FAST ? (tid + 256 * q) % (BM * GRP) : tid + 256 * q, row = it / GRP, grp = it % GRP;
+                const int it = FAST ? (tid + NT * q) % (BM * GRP) : tid + NT * q, row = it / GRP, grp = it % GRP;
                 if (!FAST && it >= BM * GRP) continue;
                 float *d = sA + row * LDS_STRIDE + grp * 8;
                 *reinterpret_cast<float4 *>(d) = make_float4(ra[q][0], ra[q][2], ra[q][4], ra[q][6]);
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             }
 #pragma unroll
             for (int q = 0; q < B_ITEMS; ++q) {
-                const int it = FAST ? (tid + 256 * q) % (BN * GRP) : tid + 256 * q, row = it / GRP, grp = it % GRP;
+                const int it = FAST ? (tid + NT * q) % (BN * GRP) : tid + NT * q, row = it / GRP, grp = it % GRP;
                 if (!FAST && it >= BN * GRP) continue;
                 float *d = sB + row * LDS_STRIDE + grp * 8;
                 *reinterpret_cast<float4 *>(d) = make_float4(rb[q][0], rb[q][2], rb[q][4], rb[q][6]);
@@ -278,8 +279,13 @@ int launch_gemm_v(const GemmArgs &g, hipStream_t st) {
         hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
     } else {
         // 64 x 256 tiles; 32-row tiles (3 blocks/CU) measured 8 % slower, BK = 16 6 % slower
+        if (getenv("PS_GEMM_BIG")) {
+            dim3 grid((unsigned)ps_cdiv(g.M, 128), (unsigned)ps_cdiv(g.N, 256));
+            hipLaunchKernelGGL((gemm_f32_kernel<2, 4, 2, 2, 32, EPI, FAST>), grid, dim3(512), 0, st, g);
+        } else {
         dim3 grid((unsigned)ps_cdiv(g.M, 64), (unsigned)ps_cdiv(g.N, 256));
         hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 2, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
+        }
     }
     PS_CHECK_LAUNCH();
     return PS_OK;

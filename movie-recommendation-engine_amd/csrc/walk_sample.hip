@@ -36,6 +36,7 @@ struct WalkArgs {
     int hs_log2;
     int stage_blocks;   // start rows of at most this many 128-byte blocks are searched in LDS
     int region_words;   // LDS words shared by the staged row (walk phase) and the hash table (count phase)
+    const unsigned char *buckets;   // 64-byte bucket records (ps_bucket_build) or NULL
 };
 
 // One Philox4x32-10 block = the uniforms of two consecutive steps of a walk: counter (node, walk, step / 2, call);
@@ -219,6 +220,55 @@ __device__ __forceinline__ void search_two(const Acc &acc, bool aliveA, eidx_t l
     if (aliveB) { if (lB >= hiB) lB = hiB - 1; if (nB < 0) nB = acc.k(lB); }
 }
 
+// The same search through the 64-byte bucket records: record lo + floor(u * deg) holds the five CDF entries starting
+// at the bucket's guide position and their destinations, so one 64-byte sector (three 16-byte loads per lane, a
+// fourth for the rare fifth candidate) replaces the dependent guide -> CDF -> destination gathers.  A lane whose answer
+// lies beyond the fifth candidate (>= 5 CDF entries inside one 1/deg-wide bucket) repeats the search the long way.
+struct BucketHit {
+    double c0, c1, c2, c3;
+    int32_t k0, k1, k2, k3;
+};
+__device__ __forceinline__ const unsigned char *bucket_of(const unsigned char *buckets, eidx_t lo, eidx_t hi, double u) {
+    const uint32_t deg = (uint32_t)(hi - lo);
+    uint32_t j = (uint32_t)(u * (double)deg);
+    if (j >= deg) j = deg - 1;
+    return buckets + (size_t)(lo + j) * 64;
+}
+__device__ __forceinline__ BucketHit bucket_load(const unsigned char *r) {
+    const double2 q0 = reinterpret_cast<const double2 *>(r)[0];
+    const double2 q1 = reinterpret_cast<const double2 *>(r)[1];
+    const int4 q2 = reinterpret_cast<const int4 *>(r)[2];
+    return BucketHit{q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q2.z, q2.w};
+}
+__device__ __forceinline__ int32_t bucket_pick(const BucketHit &h, double u) {   // -1: beyond the fourth candidate
+    return h.c0 > u ? h.k0 : h.c1 > u ? h.k1 : h.c2 > u ? h.k2 : h.c3 > u ? h.k3 : -1;
+}
+
+template <class Acc>
+__device__ __forceinline__ void search_two_buckets(const unsigned char *buckets, const Acc &acc, bool aliveA, eidx_t loA,
+                                                   eidx_t hiA, double uA, bool aliveB, eidx_t loB, eidx_t hiB, double uB,
+                                                   int32_t &nA, int32_t &nB) {
+    nA = -1;
+    nB = -1;
+    const unsigned char *rA = nullptr, *rB = nullptr;
+    BucketHit hA{}, hB{};
+    if (aliveA) { rA = bucket_of(buckets, loA, hiA, uA); hA = bucket_load(rA); }
+    if (aliveB) { rB = bucket_of(buckets, loB, hiB, uB); hB = bucket_load(rB); }
+    if (aliveA) nA = bucket_pick(hA, uA);
+    if (aliveB) nB = bucket_pick(hB, uB);
+    bool moreA = aliveA && nA < 0, moreB = aliveB && nB < 0;
+    if (__ballot(moreA || moreB) != 0ull) {                      // fifth candidate
+        if (moreA && reinterpret_cast<const double *>(rA)[6] > uA) { nA = reinterpret_cast<const int32_t *>(rA)[14]; moreA = false; }
+        if (moreB && reinterpret_cast<const double *>(rB)[6] > uB) { nB = reinterpret_cast<const int32_t *>(rB)[14]; moreB = false; }
+        if (__ballot(moreA || moreB) != 0ull) {                  // the long way for what is left
+            int32_t fA = -1, fB = -1;
+            search_two(acc, moreA, loA, hiA, uA, moreB, loB, hiB, uB, fA, fB);
+            if (moreA) nA = fA;
+            if (moreB) nB = fB;
+        }
+    }
+}
+
 // Start state of searchsorted(cdf[lo:hi], u, 'right'): with a guide table the search starts at the bucket
 // floor(u * deg) (guide = #{cdf <= (j-1)/deg} <= answer) and first scans forward; `n` counts probes.
 __device__ __forceinline__ void search_init(const int32_t *guide, const unsigned char *packed, eidx_t lo, eidx_t hi,
@@ -313,6 +363,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                 }
                 int32_t nA = -1, nB = -1;
                 if (staged && st == 0) search_two(lrow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
+                else if (a.buckets) search_two_buckets(a.buckets, grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
                 else search_two(grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
                 if (aliveA) curA = nA;
                 if (aliveB) curB = nB;
@@ -478,7 +529,7 @@ __global__ void graph_stats_kernel(const int64_t *rowptr, const int32_t *col, in
 extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                               const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
                               const double *uniforms, const int64_t *uoff, uint64_t seed, uint32_t call,
-                              const uint32_t *nodeinfo, const int32_t *guide, const void *packed,
+                              const uint32_t *nodeinfo, const int32_t *guide, const void *packed, const void *buckets,
                               int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream) {
     if (B < 0 || W <= 0 || L <= 0 || T <= 0 || V < 0) return PS_EINVAL;
     if (B == 0) return PS_OK;
@@ -487,6 +538,7 @@ extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const d
     if (rng_mode == PS_RNG_STREAM && (!uniforms || !uoff)) return PS_EINVAL;
     if ((nodeinfo == nullptr) != (guide == nullptr)) return PS_EINVAL;
     if (packed && !nodeinfo) return PS_EINVAL;
+    if (buckets && (!nodeinfo || reinterpret_cast<size_t>(buckets) % 64 != 0)) return PS_EINVAL;
     const int64_t P = (int64_t)W * L;
     if (P > 1024) return PS_EUNSUPPORTED;
     if (B == 0) return PS_OK;
@@ -495,7 +547,7 @@ extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const d
     int hs_log2 = 6;
     while ((1 << hs_log2) * 4 < 5 * P) ++hs_log2;      // table >= 1.25 P slots (load factor <= 0.8)
     WalkArgs a{rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff,
-               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0};
+               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0, reinterpret_cast<const unsigned char *>(buckets)};
     // LDS budget: the kernel holds 24 waves per CU by registers; 160 KB / 24 leaves ~6.6 KB per wave, and whatever
     // the hash table does not need of that lets longer start rows be staged.
     const int hash_words = 3 * (1 << hs_log2);

@@ -10,7 +10,7 @@ from . import native as nv
 
 
 class DeviceGraph:
-    def __init__(self, edge_index, edge_weights=None, device=None):
+    def __init__(self, edge_index, edge_weights=None, device=None, buckets=None):
         dev = nv.require_gpu() if device is None else torch.device(device)
         ei = torch.as_tensor(edge_index)
         if ei.dim() != 2 or ei.size(0) != 2:
@@ -56,6 +56,14 @@ class DeviceGraph:
             if E:
                 nv.call("ps_pack_edges", nv.ptr(self.col), nv.ptr(self.cdf), nv.ptr(self.guide), nv.i64(E),
                         nv.ptr(self.packed), nv.stream())
+            # 64-byte bucket records (one sector per walk step); skipped when they would not fit comfortably
+            self.buckets = None
+            if E and buckets is not False:
+                free = torch.cuda.mem_get_info(dev)[0]
+                if buckets is True or E * 64 < free // 2:
+                    self.buckets = torch.empty(E * 64, dtype=torch.uint8, device=dev)
+                    nv.call("ps_bucket_build", nv.ptr(self.rowptr), nv.ptr(self.col), nv.ptr(self.cdf), nv.ptr(self.guide),
+                            nv.i64(V), nv.i64(E), nv.ptr(self.buckets), nv.stream())
             flags = torch.zeros(2, dtype=torch.int64, device=dev)
             nv.call("ps_graph_stats", nv.ptr(self.rowptr), nv.ptr(self.col), nv.i64(E), nv.i64(V), nv.ptr(flags),
                                       nv.stream())
@@ -66,7 +74,8 @@ class DeviceGraph:
         del ws
 
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.cdf, self.nodeinfo, self.guide, self.packed))
+        return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.cdf, self.nodeinfo, self.guide, self.packed,
+                                                         self.buckets) if t is not None)
 
 
 class TargetCSR:

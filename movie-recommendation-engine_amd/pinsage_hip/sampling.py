@@ -120,7 +120,7 @@ def draw_numpy_uniforms(n, device):
     return t.to(device, non_blocking=True)
 
 
-def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None, use_guide=True, use_packed=True,
+def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None, use_guide=True, use_packed=True, use_buckets=True,
                 stream_nodes=None):
     """batch_sample_neighbors on the device.  rng='numpy': the global numpy stream (bit-exact with
     the reference; needs a graph without reachable sinks); rng='philox': counter-based.
@@ -168,6 +168,7 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
                                    nv.ptr(graph.nodeinfo) if use_guide else nv.ptr(None),
                                    nv.ptr(graph.guide) if use_guide else nv.ptr(None),
                                    nv.ptr(graph.packed) if (use_guide and use_packed) else nv.ptr(None),
+                                   nv.ptr(getattr(graph, "buckets", None)) if (use_guide and use_buckets) else nv.ptr(None),
                                    nv.ptr(ids), nv.ptr(counts), nv.ptr(nvalid), nv.stream())
     return NeighborBatch(ids, counts, nvalid)
 

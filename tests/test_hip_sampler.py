@@ -174,8 +174,11 @@ def test_guide_table_is_exact_on_skewed_weights():
     a = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=True)
     b = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=False)
     c = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=True, use_packed=False)
+    d = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=True, use_buckets=False)
+    e = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_packed=False, use_buckets=False)
+    assert g.buckets is not None                              # a: LDS-staged start rows + bucket records
     ids, counts, nv, _, _, _ = co.walk_sample(cg, nodes, 20, 3, 100, philox=(5, 0), threads=8)
-    for x in (a, b, c):
+    for x in (a, b, c, d, e):
         assert np.array_equal(x.ids.cpu().numpy(), ids) and np.array_equal(x.counts.cpu().numpy(), counts)
         assert np.array_equal(x.nvalid.cpu().numpy(), nv)
 

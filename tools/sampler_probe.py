@@ -20,14 +20,14 @@ def main():
         ei, ew = synth.bipartite_ratings(U, M, R, device=dev)
         g = DeviceGraph(ei, ew); del ei, ew
         nodes = torch.arange(M, device=dev)
-        for L, pk in ((1, True), (2, True), (2, False)):
-            fn = lambda: sampling.walk_sample(g, nodes, a.T, 100, L, rng="philox", seed=42, use_packed=pk)
+        for L, pk, bk in ((1, True, True), (2, True, True), (2, True, False), (2, False, False)):
+            fn = lambda: sampling.walk_sample(g, nodes, a.T, 100, L, rng="philox", seed=42, use_packed=pk, use_buckets=bk)
             fn(); torch.cuda.synchronize()
             ts = []
             for _ in range(a.reps):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record(); fn(); e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e))
-            print(f"scale {sc}: M={M} E={g.E} graph {g.nbytes()/1e6:.0f} MB  L={L} packed={pk}: {min(ts):.3f} ms -> "
+            print(f"scale {sc}: M={M} E={g.E} graph {g.nbytes()/1e6:.0f} MB  L={L} packed={pk} buckets={bk}: {min(ts):.3f} ms -> "
                   f"{min(ts)*1e6/(M*100*L):.2f} ns/step, {M*100*L/min(ts)/1e6:.2f} G steps/s", flush=True)
         del g
     if a.hamming:
