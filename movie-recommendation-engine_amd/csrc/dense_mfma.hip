@@ -139,23 +139,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
             stash();
             __syncthreads();
             if (k0 + BK < K) fetch(k0 + BK);
-#pragma unroll
-            for (int grp = 0; grp < GRP; ++grp) {
-                float4 fa[TM], fb[TN];
+            // fragments of group g+1 are requested BEFORE group g's MFMAs: the two waves of a SIMD run in lockstep
+            // (same barriers, round-robin issue), so an LDS round trip taken between groups idles the MFMA pipe for
+            // both of them -- measured 65 % pipe use without this prefetch
+            float4 fa[2][TM], fb[2][TN];
+            auto frags = [&](int grp, int s) {
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
-                    fa[a] = *reinterpret_cast<const float4 *>(sA + ((wm * TM + a) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
+                    fa[s][a] = *reinterpret_cast<const float4 *>(sA + ((wm * TM + a) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    fb[b] = *reinterpret_cast<const float4 *>(sB + ((wn * TN + b) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
+                    fb[s][b] = *reinterpret_cast<const float4 *>(sB + ((wn * TN + b) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
+            };
+            frags(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);           // keep this order: DS reads ...
+#pragma unroll
+            for (int grp = 0; grp < GRP; ++grp) {
+                const int s = grp & 1;
+                if (grp + 1 < GRP) {
+                    frags(grp + 1, s ^ 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // ... next group's DS reads first,
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);   // ... then this group's MFMAs
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
 #pragma unroll
                     for (int a = 0; a < TM; ++a) {
-                        const float av = t == 0 ? fa[a].x : t == 1 ? fa[a].y : t == 2 ? fa[a].z : fa[a].w;
+                        const float av = t == 0 ? fa[s][a].x : t == 1 ? fa[s][a].y : t == 2 ? fa[s][a].z : fa[s][a].w;
 #pragma unroll
                         for (int b = 0; b < TN; ++b) {
-                            const float bv = t == 0 ? fb[b].x : t == 1 ? fb[b].y : t == 2 ? fb[b].z : fb[b].w;
+                            const float bv = t == 0 ? fb[s][b].x : t == 1 ? fb[s][b].y : t == 2 ? fb[s][b].z : fb[s][b].w;
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
                         }
                     }

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""HBM traffic per C-ABI call from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB per launch as reported).
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.txt> <out.json> <steps> [label]"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+fetch_dir, write_dir, out_txt, out_json, steps = sys.argv[1:6]
+label = sys.argv[6] if len(sys.argv) > 6 else out_txt
+steps = int(steps)
+
+
+def load(d, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    return acc
+
+
+F, Wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+names = sorted(set(F) | set(Wr), key=lambda k: -(F[k][0] + Wr[k][0]))
+lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `bench.py --steps %d --warmup 1 --no-cpu-baseline`" % steps,
+         "values: KB per launch (mean over launches), as reported (FETCH_SIZE = TCC_EA0_RDREQ x 64 B; no wide-stream correction applied)", ""]
+for k in names:
+    own = any(t in k for t in ("walk_", "gemm_f32", "hamming", "importance_pool", "topk_merge", "cdf_", "guide_", "pack_", "bucket_", "gather_kernel", "mt_", "spmm"))
+    if not own:
+        continue
+    nf, nw = F[k][1] or 1, Wr[k][1] or 1
+    lines.append(f"{k[:48]:48s} launches={F[k][1]:3d} FETCH_SIZE={F[k][0] / nf:12.1f} KB  WRITE_SIZE={Wr[k][0] / nw:12.1f} KB")
+open(out_txt, "w").write("\n".join(lines) + "\n")
+
+
+def per_launch(pred):
+    tot = 0.0
+    for k in names:
+        if pred(k):
+            tot += (F[k][0] / (F[k][1] or 1) + Wr[k][0] / (Wr[k][1] or 1)) * 1024.0
+    return tot
+
+
+out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps {steps} --warmup 1 --no-cpu-baseline ({label})",
+       "units": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB * 1024, as reported (no gfx950 wide-stream correction applied: narrow gathers are uncalibrated)",
+       "ps_walk_sample": per_launch(lambda k: k.startswith("walk_sample_kernel")),
+       "ps_importance_pool": per_launch(lambda k: k.startswith("importance_pool_kernel")),
+       "ps_linear": per_launch(lambda k: k.startswith("gemm_f32_kernel") and ", 0, " in k),
+       "ps_lsh_encode": per_launch(lambda k: k.startswith("gemm_f32_kernel") and ", 1, " in k),
+       "ps_hamming_topk": per_launch(lambda k: k.startswith("hamming_scan_kernel") or k.startswith("topk_merge_kernel"))}
+json.dump(out, open(out_json, "w"), indent=1)
+print(open(out_txt).read())
