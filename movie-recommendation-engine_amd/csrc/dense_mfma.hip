@@ -46,6 +46,20 @@ __device__ __forceinline__ void load8(const float *base, bool row_ok, int k, int
     }
 }
 
+// Sum over the 32 lanes of each wave half, valid in lanes 16..31 / 48..63, with DPP only (the LDS crossbar that
+// __shfl_xor goes through is shared by the CU's waves: 160 shuffles per wave cost ~17 us per launch).
+#define PS_DPP_ADD(v, ctrl, rows) \
+    (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rows), 0xf, true))
+__device__ __forceinline__ float half_sum32(float v) {
+    PS_DPP_ADD(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]: lane ^ 1
+    PS_DPP_ADD(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]: lane ^ 2
+    PS_DPP_ADD(v, 0x141, 0xf);   // row_half_mirror: the other quad of the 8
+    PS_DPP_ADD(v, 0x140, 0xf);   // row_mirror: the other 8 of the 16
+    PS_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15 -> rows 1 and 3 add the row before them
+    return v;
+}
+#undef PS_DPP_ADD
+
 // FAST: every operand is 16-B aligned with K % BK == 0 -> unconditional float4 loads (rows past the end are
 // clamped to the last valid row; their results are never stored), so nothing branches or waits inside the
 // fetch and the loads stay in flight under the MFMAs.  The general variant predicates every element.
@@ -222,10 +236,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
                 float ss = 0.f;
 #pragma unroll
                 for (int b = 0; b < TN; ++b) ss = fmaf(acc[a][b][r], acc[a][b][r], ss);
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);   // over the 32 columns of the half
+                ss = half_sum32(ss);                                            // over the 32 columns of the half
                 const int rowl = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (li == 0) sRed[rowl * WN + wn] = ss;
+                if (li == 16) sRed[rowl * WN + wn] = ss;
             }
         __syncthreads();
 #pragma unroll
