@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Device MT19937 (numpy legacy stream) generation rate at the bench size (59047 x 100 x 2 doubles)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "movie-recommendation-engine_amd"))
+import numpy as np, torch
+from pinsage_hip import dense
+dev = torch.device("cuda")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 59047 * 200
+np.random.seed(0)
+st0 = np.random.get_state()
+out = dense.mt19937_random_sample(n, dev)
+ref = np.random.RandomState(0).random_sample(n)
+print("matches numpy:", np.array_equal(out.cpu().numpy(), ref))
+ts = []
+for _ in range(5):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); dense.mt19937_random_sample(n, dev); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+print(f"n={n}: min {min(ts):.3f} ms -> {n / min(ts) / 1e6:.2f} G doubles/s")
