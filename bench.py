@@ -264,6 +264,14 @@ def main():
                     "algorithmic_per_launch": samp_bytes if dom == "ps_walk_sample" else None,
                     "steps_per_launch": (steps0 + steps1) / 2 if dom == "ps_walk_sample" else None,
                     "largest_kernel_by_time": dominant}
+        # device kernels behind each C-ABI call (the rows of profiles/*/kernel_stats.csv the timings agree with)
+        symbols = {"ps_walk_sample": ["walk_sample_kernel<4>"], "ps_importance_pool": ["importance_pool_kernel<4>"],
+                   "ps_linear": ["gemm_f32_kernel<2,2,1,2,32,0,true> (input_proj: no row norm, 64x128 tiles)",
+                                 "gemm_f32_kernel<1,4,2,2,32,0,true> (layers + output_proj: fused L2 norm, 64x256 tiles)"],
+                   "ps_lsh_encode": ["gemm_f32_kernel<2,2,1,2,32,1,true>"],
+                   "ps_hamming_topk": ["hamming_scan_kernel<16,4>", "topk_merge_kernel"]}
+        for n, k in kern.items():
+            k["device_kernels"] = symbols.get(n, [])
         for k in kern.values():
             div = 1e12 if k["bound"] == "mfma" else 1e9
             k["achieved"] = k["achieved"] / div

@@ -19,7 +19,6 @@
 // in registers while staging (two float4 global loads per row-group), global loads for the next
 // K step are in flight while the current one is multiplied.
 #include "ps_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -304,13 +303,15 @@ int launch_gemm_v(const GemmArgs &g, hipStream_t st) {
         dim3 grid((unsigned)ps_cdiv(g.M, 64), 1);
         hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
     } else {
-        // 64 x 256 tiles; 32-row tiles (3 blocks/CU) measured 8 % slower, BK = 16 6 % slower
-        if (getenv("PS_GEMM_BIG")) {
-            dim3 grid((unsigned)ps_cdiv(g.M, 128), (unsigned)ps_cdiv(g.N, 256));
-            hipLaunchKernelGGL((gemm_f32_kernel<2, 4, 2, 2, 32, EPI, FAST>), grid, dim3(512), 0, st, g);
+        if (!(g.flags & PS_L2NORM)) {
+            // no row reduction in the epilogue: 64 x 128 tiles (twice the resident waves) measured 2-7 % faster
+            dim3 grid((unsigned)ps_cdiv(g.M, 64), (unsigned)ps_cdiv(g.N, 128));
+            hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
         } else {
-        dim3 grid((unsigned)ps_cdiv(g.M, 64), (unsigned)ps_cdiv(g.N, 256));
-        hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 2, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
+            // 64 x 256 tiles (whole rows for the fused L2 norm); 32-row tiles measured 8 % slower, BK = 16 6 % slower,
+            // 128 x 256 tiles / 8 waves per block / a double-buffered BK = 16 image no faster
+            dim3 grid((unsigned)ps_cdiv(g.M, 64), (unsigned)ps_cdiv(g.N, 256));
+            hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 2, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
         }
     }
     PS_CHECK_LAUNCH();
