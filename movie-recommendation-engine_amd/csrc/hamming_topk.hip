@@ -137,6 +137,70 @@ __global__ __launch_bounds__(256) void hamming_scan_kernel(const uint32_t *__res
     }
 }
 
+// Merge of P candidate lists: one wave per query, every candidate finds its own rank.  Candidate c (list c / k,
+// slot c % k) sits in lane c % 64, register c / 64; its rank = #candidates with a smaller (distance, id) (ties by
+// candidate number, so ranks are a permutation), counted by broadcasting every candidate once through v_readlane --
+// no LDS, no shuffles (the selection kernel below spends k * 18 LDS-crossbar shuffles per query).
+template <int CPL>
+__global__ __launch_bounds__(256) void topk_rank_merge_kernel(const int32_t *__restrict__ din, const int64_t *__restrict__ iin,
+                                                              int P, int64_t nq, int k, int32_t *__restrict__ dout,
+                                                              int64_t *__restrict__ iout) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int n = P * k;
+    for (int64_t qi = wave; qi < nq; qi += nw) {
+        int32_t kd[CPL];
+        int64_t kid[CPL];                                               // -1 = no candidate (sorts last)
+        int rank[CPL];
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            const int c = r * 64 + lane;
+            kd[r] = 0x7fffffff;
+            kid[r] = -1;
+            rank[r] = 0;
+            if (c < n) {
+                const int p = c / k, t = c - p * k;
+                const int64_t o = ((int64_t)p * nq + qi) * k + t;
+                kid[r] = iin[o];
+                if (kid[r] >= 0) kd[r] = din[o];
+            }
+        }
+        for (int j = 0; j < n; ++j) {                                   // wave-uniform loop
+            const int jr = j >> 6, jl = j & 63;
+            int32_t dj = 0;
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int r = 0; r < CPL; ++r)
+                if (r == jr) {
+                    dj = __builtin_amdgcn_readlane(kd[r], jl);
+                    lo = __builtin_amdgcn_readlane((uint32_t)kid[r], jl);
+                    hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)kid[r] >> 32), jl);
+                }
+            const int64_t idj = (int64_t)(((uint64_t)hi << 32) | lo);
+            if (idj < 0) continue;                                      // missing candidates precede nobody
+#pragma unroll
+            for (int r = 0; r < CPL; ++r) {
+                const int c = r * 64 + lane;
+                const bool same = (dj == kd[r]) & (idj == kid[r]);
+                const bool less = (dj < kd[r]) | ((dj == kd[r]) & (idj < kid[r]));
+                rank[r] += (kid[r] < 0) | less | (same & (j < c));
+            }
+        }
+        int nvalid = 0;
+#pragma unroll
+        for (int r = 0; r < CPL; ++r) {
+            const bool has = kid[r] >= 0;
+            nvalid += __popcll(__ballot(has));
+            if (has && rank[r] < k) {
+                dout[qi * k + rank[r]] = kd[r];
+                iout[qi * k + rank[r]] = kid[r];
+            }
+        }
+        for (int t = nvalid + lane; t < k; t += 64) { dout[qi * k + t] = 0x7fffffff; iout[qi * k + t] = -1; }
+    }
+}
+
 // one wave per query: k rounds of (lane-local min over strided candidates) + wave min-reduce.
 __global__ __launch_bounds__(256) void topk_merge_kernel(const int32_t *__restrict__ din, const int64_t *__restrict__ iin,
                                                          int P, int64_t nq, int k, int32_t *__restrict__ dout,
@@ -221,8 +285,12 @@ extern "C" int ps_topk_merge(const int32_t *dist_in, const int64_t *ids_in, int 
     if (!dist_in || !ids_in || !dist || !ids) return PS_EINVAL;
     int64_t grid = ps_cdiv(nq, 4);
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)grid), dim3(256), 0, ps_stream(stream), dist_in, ids_in, P, nq,
-                       k, dist, ids);
+    const int64_t n = (int64_t)P * k;
+    hipStream_t st = ps_stream(stream);
+    if (n <= 64) hipLaunchKernelGGL(topk_rank_merge_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, dist_in, ids_in, P, nq, k, dist, ids);
+    else if (n <= 128) hipLaunchKernelGGL(topk_rank_merge_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, dist_in, ids_in, P, nq, k, dist, ids);
+    else if (n <= 256) hipLaunchKernelGGL(topk_rank_merge_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, dist_in, ids_in, P, nq, k, dist, ids);
+    else hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)grid), dim3(256), 0, st, dist_in, ids_in, P, nq, k, dist, ids);
     PS_CHECK_LAUNCH();
     return PS_OK;
 }

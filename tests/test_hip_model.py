@@ -395,3 +395,27 @@ def test_graphconv_edge_branch_hip_vs_torch():
     e = m(x.cuda(), edge_index=ei.cuda())
     e.square().sum().backward()
     assert m.convs[0].lin_neigh.weight.grad is not None
+
+
+@pytest.mark.parametrize("P,k", [(2, 11), (5, 11), (8, 11), (20, 11), (30, 11), (3, 1), (4, 64)])
+def test_topk_merge_vs_lexsort(P, k):
+    """ps_topk_merge over P candidate lists (rank merge for P*k <= 256, selection kernel beyond) vs a numpy
+    (distance, id) sort; lists may be short (-1 / INT32_MAX padding) and distances tie across lists."""
+    from pinsage_hip import dense
+    rs = np.random.RandomState(P * 100 + k)
+    nq = 257
+    d = rs.randint(0, 40, size=(P, nq, k)).astype(np.int32)
+    ids = np.stack([rs.permutation(100000)[:P * k].reshape(P, k) for _ in range(nq)], axis=1).astype(np.int64)
+    short = rs.rand(P, nq, k) < 0.15
+    ids[short] = -1
+    d[short] = 0x7fffffff
+    ids[:, 0] = -1; d[:, 0] = 0x7fffffff                                  # a query without any candidate
+    dm, im = dense.topk_merge(torch.from_numpy(d).cuda(), torch.from_numpy(ids).cuda())
+    dm, im = dm.cpu().numpy(), im.cpu().numpy()
+    for q in range(nq):
+        dd, ii = d[:, q].reshape(-1), ids[:, q].reshape(-1)
+        ok = ii >= 0
+        order = np.lexsort((ii[ok], dd[ok]))[:k]
+        ed = np.full(k, 0x7fffffff, np.int32); ei = np.full(k, -1, np.int64)
+        ed[:order.size] = dd[ok][order]; ei[:order.size] = ii[ok][order]
+        assert np.array_equal(dm[q], ed) and np.array_equal(im[q], ei), q
