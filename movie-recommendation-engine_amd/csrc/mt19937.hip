@@ -10,8 +10,8 @@
 // The recurrence is serial (parallelism 227 per 624 words), so the stream is cut into 2^17-word chunks that
 // independent workgroups generate; the 624-word window at the start of every chunk comes from GF(2) jump-ahead:
 // with g(t) = t^(2^m) mod phi(t) (pinsage_hip/mtjump.py), the window 2^m words ahead is the XOR of the windows
-// at the offsets i with g_i = 1 -- one workgroup expands 34 blocks of the sequence to global memory, then 8
-// workgroups each XOR the windows selected by 1/8 of the polynomial (the 8 partial windows are XORed by whoever
+// at the offsets i with g_i = 1 -- one workgroup expands 34 blocks of the sequence to global memory, then 24
+// workgroups each XOR the windows selected by 1/24 of the polynomial (the 24 partial windows are XORed by whoever
 // reads the window next).  Chunk windows are produced by doubling (1 -> 2 -> 4 ... windows per round).
 // Without polynomials (or for short requests) a single workgroup generates the stream serially.
 #include "ps_common.h"
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void mt_prepare_kernel(const uint32_t *state_i
 }
 
 // A window is stored as JP partial vectors whose XOR is the 624-word window (a plain window = itself + zeros).
-constexpr int JP = 8;                                    // workgroups per jump
+constexpr int JP = 24;                                   // workgroups per jump
 constexpr int PW = MT_N / JP;                            // polynomial words per part (78 -> 2496 bits)
 constexpr int SEQ_PAD = 34 * MT_N;                       // expanded sequence per source, whole blocks
 static_assert(SEQ_PAD >= DEG + MT_N && JP * PW == MT_N, "jump geometry");
@@ -129,36 +129,49 @@ __global__ __launch_bounds__(256) void mt_expand_kernel(const uint32_t *src_part
 }
 
 // dst_parts[b][p] = XOR over the set bits i of poly words [p*PW, (p+1)*PW) of seq[b][i .. i+624): part p of the
-// window 2^m words after source b (poly = coefficients of t^(2^m) mod phi, 624 words, LSB first)
-__global__ __launch_bounds__(640) void mt_combine_kernel(const uint32_t *seq, const uint32_t *poly, uint32_t *dst_parts) {
+// window 2^m words after source b (poly = coefficients of t^(2^m) mod phi, 624 words, LSB first).
+// The set bits are wave-uniform, so the bit scan is scalar work that every wave repeats: each lane therefore owns FOUR
+// output words (t, t+156, t+312, t+468 -> two ds_read2_b32 per set bit) and a part is only 832 polynomial bits, which
+// keeps a block's serial chain short while few windows exist (first doubling rounds) -- 8 parts x 624 single-word lanes
+// took 25 us per block and 2x the instruction issue.
+constexpr int CT = MT_N / 4;                             // 156 active lanes per block
+__global__ __launch_bounds__(192) void mt_combine_kernel(const uint32_t *seq, const uint32_t *poly, uint32_t *dst_parts) {
     __shared__ uint32_t sq[PW * 32 + MT_N + 8];
-    __shared__ uint32_t pl[PW + 1];
+    __shared__ uint32_t pl[PW];
     const int t = threadIdx.x;
     const int b = blockIdx.x / JP, part = blockIdx.x % JP;
     const uint32_t *s = seq + (size_t)b * SEQ_PAD + part * PW * 32;
-    for (int i = t; i < PW * 32 + MT_N; i += 640) sq[i] = s[i];
+    for (int i = t; i < PW * 32 + MT_N; i += 192) sq[i] = s[i];
     if (t < PW) pl[t] = poly[part * PW + t];
-    if (t == 0) pl[PW] = 0u;
     __syncthreads();
-    if (t < MT_N) {
-        // the set bits are wave-uniform (scalar bit scan); eight independent LDS reads are in flight per lane
-        uint32_t acc0 = 0, acc1 = 0;
+    if (t < CT) {
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         for (int w = 0; w < PW; ++w) {
             uint32_t bits = pl[w];
             const uint32_t *p = sq + w * 32 + t;
             while (bits) {
-                uint32_t v[8];
+                uint32_t v[2][4];                 // two set bits per iteration (eight measured slower: 0.97 vs 0.80 ms)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int bu = bits ? __builtin_ctz(bits) : 0;
-                    v[u] = bits ? p[bu] : 0u;
+                for (int u = 0; u < 2; ++u) {
+                    const bool on = bits != 0u;
+                    const int bu = on ? __builtin_ctz(bits) : 0;
+                    v[u][0] = on ? p[bu] : 0u;
+                    v[u][1] = on ? p[bu + CT] : 0u;
+                    v[u][2] = on ? p[bu + 2 * CT] : 0u;
+                    v[u][3] = on ? p[bu + 3 * CT] : 0u;
                     bits &= bits - 1u;            // 0 stays 0
                 }
-                acc0 ^= (v[0] ^ v[1]) ^ (v[2] ^ v[3]);
-                acc1 ^= (v[4] ^ v[5]) ^ (v[6] ^ v[7]);
+                a0 ^= v[0][0] ^ v[1][0];
+                a1 ^= v[0][1] ^ v[1][1];
+                a2 ^= v[0][2] ^ v[1][2];
+                a3 ^= v[0][3] ^ v[1][3];
             }
         }
-        dst_parts[((size_t)b * JP + part) * MT_N + t] = acc0 ^ acc1;
+        uint32_t *d = dst_parts + ((size_t)b * JP + part) * MT_N + t;
+        d[0] = a0;
+        d[CT] = a1;
+        d[2 * CT] = a2;
+        d[3 * CT] = a3;
     }
 }
 
@@ -289,7 +302,7 @@ extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, in
         if (!((p.c0 >> b) & 1)) continue;
         hipLaunchKernelGGL(mt_expand_kernel, dim3(1), dim3(256), 0, st, cur, seqs);
         PS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(mt_combine_kernel, dim3(JP), dim3(640), 0, st, seqs, jump_polys + (size_t)(CHUNK_LOG2 + b) * MT_N, nxt);
+        hipLaunchKernelGGL(mt_combine_kernel, dim3(JP), dim3(192), 0, st, seqs, jump_polys + (size_t)(CHUNK_LOG2 + b) * MT_N, nxt);
         PS_CHECK_LAUNCH();
         uint32_t *t = cur; cur = nxt; nxt = t;
     }
@@ -300,7 +313,7 @@ extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, in
         const int64_t make = (K - have) < have ? (K - have) : have;
         hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)make), dim3(256), 0, st, states, seqs);
         PS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(mt_combine_kernel, dim3((unsigned)(make * JP)), dim3(640), 0, st, seqs,
+        hipLaunchKernelGGL(mt_combine_kernel, dim3((unsigned)(make * JP)), dim3(192), 0, st, seqs,
                            jump_polys + (size_t)(CHUNK_LOG2 + m) * MT_N, states + (size_t)have * WSZ);
         PS_CHECK_LAUNCH();
     }
