@@ -35,15 +35,14 @@ __device__ __forceinline__ uint32_t temper(uint32_t y) {
     return y;
 }
 
-// next 624 words from the previous 624 (o -> n), all threads of the block; 3 dependency phases + the last word
+// next 624 words from the previous 624 (o -> n), all threads of the block; 3 dependency phases
 __device__ __forceinline__ void next_block(const uint32_t *o, uint32_t *n, int t) {
     if (t < 227) n[t] = o[t + MT_M] ^ twist(o[t], o[t + 1]);
     __syncthreads();
     if (t < 227) { const int i = 227 + t; n[i] = n[i - 227] ^ twist(o[i], o[i + 1]); }
     __syncthreads();
     if (t < 169) { const int i = 454 + t; n[i] = n[i - 227] ^ twist(o[i], o[i + 1]); }
-    __syncthreads();
-    if (t == 0) n[623] = n[396] ^ twist(o[623], n[0]);
+    else if (t == 169) n[623] = n[396] ^ twist(o[623], n[0]);      // its inputs are phase-1 / phase-2 words
     __syncthreads();
 }
 
