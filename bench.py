@@ -272,6 +272,9 @@ def main():
                    "ps_hamming_topk": ["hamming_scan_kernel<16,4>", "topk_merge_kernel"]}
         for n, k in kern.items():
             k["device_kernels"] = symbols.get(n, [])
+        if "ps_importance_pool" in kern:
+            kern["ps_importance_pool"]["note"] = ("algorithmic bytes = gathered rows + output (SURVEY 8d); the hidden rows (M x H x 4 = "
+                                                   "60 MB) stay in L2/MALL, so the gathers are not HBM traffic and frac can exceed 1 at large T")
         for k in kern.values():
             div = 1e12 if k["bound"] == "mfma" else 1e9
             k["achieved"] = k["achieved"] / div
