@@ -24,24 +24,42 @@ __global__ __launch_bounds__(256) void importance_pool_kernel(const float *__res
     const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
     const int chunk = 64 * VEC;
     for (int64_t i = wave; i < B; i += nwaves) {
+        // the row's metadata is requested at once (T <= 64: one id / count / weight per lane, kept in registers), so the
+        // chain before the row gathers is one global round trip, not one per quantity
+        const bool small = T <= 64;
+        int32_t id0 = -1, cnt0 = 0;
+        float wt0 = 0.f;
+        if (small && lane < T) {
+            id0 = ids[i * T + lane];
+            if (counts) cnt0 = counts[i * T + lane];
+            if (wts) wt0 = wts[i * T + lane];
+        }
         const int k = __builtin_amdgcn_readfirstlane(nvalid[i]);
         // ---- weights: total of the kept counts (reference: weights = count / sum(top counts)) ----
         int tot = 0;
-        for (int j0 = 0; j0 < k; j0 += 64) {
-            const int j = j0 + lane;
-            tot += (counts && j < k) ? counts[i * T + j] : 0;
+        if (small) {
+            tot = lane < k ? cnt0 : 0;
+        } else {
+            for (int j0 = 0; j0 < k; j0 += 64) {
+                const int j = j0 + lane;
+                tot += (counts && j < k) ? counts[i * T + j] : 0;
+            }
         }
         tot = ps_wave_sum_i32(tot);
         float wsum = 0.f;
-        for (int j0 = 0; j0 < k; j0 += 64) {
-            const int j = j0 + lane;
-            float wj = 0.f;
-            if (j < k) {
-                const int32_t id = ids[i * T + j];
-                if (id >= 0 && (int64_t)id <= max_idx)
-                    wj = wts ? wts[i * T + j] : (float)((double)counts[i * T + j] / (double)tot);
+        if (small) {
+            if (lane < k && id0 >= 0 && (int64_t)id0 <= max_idx) wsum = wts ? wt0 : (float)((double)cnt0 / (double)tot);
+        } else {
+            for (int j0 = 0; j0 < k; j0 += 64) {
+                const int j = j0 + lane;
+                float wj = 0.f;
+                if (j < k) {
+                    const int32_t id = ids[i * T + j];
+                    if (id >= 0 && (int64_t)id <= max_idx)
+                        wj = wts ? wts[i * T + j] : (float)((double)counts[i * T + j] / (double)tot);
+                }
+                wsum += wj;
             }
-            wsum += wj;
         }
         wsum = ps_wave_sum_f32(wsum);
         const bool do_norm = renorm && wsum > 0.f;        // w /= w.sum() only if sum > 0 (pinsage.py:141-143)
@@ -57,9 +75,10 @@ __global__ __launch_bounds__(256) void importance_pool_kernel(const float *__res
                 int32_t myid = -1;
                 float myw = 0.f;
                 if (jj < k) {
-                    myid = ids[i * T + jj];
+                    myid = small ? id0 : ids[i * T + jj];
                     if (myid >= 0 && (int64_t)myid <= max_idx) {
-                        myw = wts ? wts[i * T + jj] : (float)((double)counts[i * T + jj] / (double)tot);
+                        if (small) myw = wts ? wt0 : (float)((double)cnt0 / (double)tot);
+                        else myw = wts ? wts[i * T + jj] : (float)((double)counts[i * T + jj] / (double)tot);
                         if (do_norm) myw = myw / wsum;
                     } else {
                         myid = -1;

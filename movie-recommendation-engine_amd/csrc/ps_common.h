@@ -27,13 +27,25 @@ __device__ __forceinline__ void ps_wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Wave-wide sums, result in every lane.  DPP only (quad_perm, row_half_mirror, row_mirror, row_bcast:15 / :31, then a
+// v_readlane of lane 63): __shfl_xor goes through the LDS crossbar, which all waves of a CU share.
+#define PS_DPP_MOV(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rows), 0xf, true)
 __device__ __forceinline__ int ps_wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += PS_DPP_MOV(v, 0xB1, 0xf);
+    v += PS_DPP_MOV(v, 0x4E, 0xf);
+    v += PS_DPP_MOV(v, 0x141, 0xf);
+    v += PS_DPP_MOV(v, 0x140, 0xf);
+    v += PS_DPP_MOV(v, 0x142, 0xa);
+    v += PS_DPP_MOV(v, 0x143, 0xc);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ float ps_wave_sum_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __builtin_bit_cast(float, PS_DPP_MOV(__builtin_bit_cast(int, v), 0xB1, 0xf));
+    v += __builtin_bit_cast(float, PS_DPP_MOV(__builtin_bit_cast(int, v), 0x4E, 0xf));
+    v += __builtin_bit_cast(float, PS_DPP_MOV(__builtin_bit_cast(int, v), 0x141, 0xf));
+    v += __builtin_bit_cast(float, PS_DPP_MOV(__builtin_bit_cast(int, v), 0x140, 0xf));
+    v += __builtin_bit_cast(float, PS_DPP_MOV(__builtin_bit_cast(int, v), 0x142, 0xa));
+    v += __builtin_bit_cast(float, PS_DPP_MOV(__builtin_bit_cast(int, v), 0x143, 0xc));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+#undef PS_DPP_MOV
