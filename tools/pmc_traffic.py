@@ -34,6 +34,7 @@ open(out_txt, "w").write("\n".join(lines) + "\n")
 
 
 def per_launch(pred):
+    """kernels that one call launches together (scan + merge): per-launch means add up"""
     tot = 0.0
     for k in names:
         if pred(k):
@@ -41,12 +42,19 @@ def per_launch(pred):
     return tot
 
 
+def per_call(pred):
+    """kernel variants of which a call launches ONE (tile shapes of the GEMM): total bytes / total launches"""
+    b = sum(F[k][0] + Wr[k][0] for k in names if pred(k)) * 1024.0
+    n = sum(max(F[k][1], Wr[k][1]) for k in names if pred(k))
+    return b / max(n, 1)
+
+
 out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps {steps} --warmup 1 --no-cpu-baseline ({label})",
        "units": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB * 1024, as reported (no gfx950 wide-stream correction applied: narrow gathers are uncalibrated)",
        "ps_walk_sample": per_launch(lambda k: k.startswith("walk_sample_kernel")),
        "ps_importance_pool": per_launch(lambda k: k.startswith("importance_pool_kernel")),
-       "ps_linear": per_launch(lambda k: k.startswith("gemm_f32_kernel") and ", 0, " in k),
-       "ps_lsh_encode": per_launch(lambda k: k.startswith("gemm_f32_kernel") and ", 1, " in k),
+       "ps_linear": per_call(lambda k: k.startswith("gemm_f32_kernel") and ", 0, " in k),
+       "ps_lsh_encode": per_call(lambda k: k.startswith("gemm_f32_kernel") and ", 1, " in k),
        "ps_hamming_topk": per_launch(lambda k: k.startswith("hamming_scan_kernel") or k.startswith("topk_merge_kernel"))}
 json.dump(out, open(out_json, "w"), indent=1)
 print(open(out_txt).read())
