@@ -307,6 +307,11 @@ int launch_gemm_v(const GemmArgs &g, hipStream_t st) {
             // no row reduction in the epilogue: 64 x 128 tiles (twice the resident waves) measured 2-7 % faster
             dim3 grid((unsigned)ps_cdiv(g.M, 64), (unsigned)ps_cdiv(g.N, 128));
             hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
+        } else if (g.M < 64 * 384) {
+            // a shard of a multi-GPU job (59 047 / 8 rows = 116 tiles of 64 rows) would leave half of the CUs idle:
+            // 32-row tiles
+            dim3 grid((unsigned)ps_cdiv(g.M, 32), (unsigned)ps_cdiv(g.N, 256));
+            hipLaunchKernelGGL((gemm_f32_kernel<1, 4, 1, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
         } else {
             // 64 x 256 tiles (whole rows for the fused L2 norm); 32-row tiles measured 8 % slower, BK = 16 6 % slower,
             // 128 x 256 tiles / 8 waves per block / a double-buffered BK = 16 image no faster
