@@ -281,3 +281,30 @@ def test_hard_negatives_match_reference_semantics():
         assert got.shape == (5, nh) and got.dtype == torch.int64
         assert np.array_equal(got.numpy(), ref), (lo, hi)
         assert np.random.random_sample() == tail
+
+
+def test_bucket_records_match_their_definition():
+    """ps_bucket_build: record lo+j = the five CDF entries from guide[lo+j] on and their destinations (past the row
+    end: 2.0 / the row's last destination) -- checked field by field against cdf / col / guide."""
+    from pinsage_hip.graph import DeviceGraph
+    ei, ew = bipartite_graph(60, 40, 900, 3, "half")
+    g = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew), buckets=True)
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    cdf, guide = g.cdf.cpu().numpy(), g.guide.cpu().numpy()
+    raw = g.buckets.cpu().numpy().reshape(g.E, 64)
+    c = raw[:, :32].copy().view(np.float64)                              # c0..c3
+    k = raw[:, 32:48].copy().view(np.int32)                              # k0..k3
+    c4 = raw[:, 48:56].copy().view(np.float64)[:, 0]
+    k4 = raw[:, 56:60].copy().view(np.int32)[:, 0]
+    cs = np.concatenate([c, c4[:, None]], axis=1)
+    ks = np.concatenate([k, k4[:, None]], axis=1)
+    for v in range(g.V):
+        lo, hi = int(rowptr[v]), int(rowptr[v + 1])
+        for e in range(lo, hi):
+            first = lo + int(guide[e])
+            for i in range(5):
+                idx = first + i
+                if idx < hi:
+                    assert cs[e, i] == cdf[idx] and ks[e, i] == col[idx]
+                else:
+                    assert cs[e, i] == 2.0 and ks[e, i] == col[hi - 1]
