@@ -122,12 +122,16 @@ int ps_uniform_offsets(const int64_t *rowptr, int64_t V, const int64_t *starts, 
  * skipped, then n doubles written; the state after skip + n draws comes back (what np.random.set_state needs).
  * Replaces the global-RNG draws of np.random.choice at utils/random_walk.py:79.
  * jump_polys uint32[jump_levels, 624] (row m = t^(2^m) mod phi over GF(2), from pinsage_hip/mtjump.py) enables
- * the parallel path (2^16-word chunks generated by independent workgroups, windows by jump-ahead); with NULL
- * polynomials / workspace a single workgroup generates the stream serially (skip must be 0). */
+ * the parallel path (2^c-word chunks, c = ps_mt19937_chunk_log2(), generated by independent workgroups, windows by
+ * jump-ahead); with NULL polynomials / workspace a single workgroup generates the stream serially (skip must be 0).
+ * radix_polys uint32[radix_levels, 15, 624] (entry (i, j-1) = t^(j * 2^(c + 4i)) mod phi, optional): the chunk windows
+ * are then produced in radix-16 rounds instead of by doubling. */
+int ps_mt19937_chunk_log2(void);
 size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n);
 int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,
                              uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys, int jump_levels,
-                             void *workspace, size_t workspace_bytes, ps_stream_t stream);
+                             const uint32_t *radix_polys, int radix_levels, void *workspace, size_t workspace_bytes,
+                             ps_stream_t stream);
 
 /* ---- a5 / a9: ImportancePooling.forward (model/pinsage.py:101-150); Weighted/Mean/Importance
  * aggregators' gather + weighted reduce (model/aggregators.py:13-91,233-287).

@@ -134,14 +134,12 @@ __global__ __launch_bounds__(256) void mt_expand_kernel(const uint32_t *src_part
 // keeps a block's serial chain short while few windows exist (first doubling rounds) -- 8 parts x 624 single-word lanes
 // took 25 us per block and 2x the instruction issue.
 constexpr int CT = MT_N / 4;                             // 156 active lanes per block
-__global__ __launch_bounds__(192) void mt_combine_kernel(const uint32_t *seq, const uint32_t *poly, uint32_t *dst_parts) {
+__device__ __forceinline__ void combine_part(const uint32_t *s, const uint32_t *poly_part, uint32_t *dst) {
     __shared__ uint32_t sq[PW * 32 + MT_N + 8];
     __shared__ uint32_t pl[PW];
     const int t = threadIdx.x;
-    const int b = blockIdx.x / JP, part = blockIdx.x % JP;
-    const uint32_t *s = seq + (size_t)b * SEQ_PAD + part * PW * 32;
     for (int i = t; i < PW * 32 + MT_N; i += 192) sq[i] = s[i];
-    if (t < PW) pl[t] = poly[part * PW + t];
+    if (t < PW) pl[t] = poly_part[t];
     __syncthreads();
     if (t < CT) {
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -166,12 +164,27 @@ __global__ __launch_bounds__(192) void mt_combine_kernel(const uint32_t *seq, co
                 a3 ^= v[0][3] ^ v[1][3];
             }
         }
-        uint32_t *d = dst_parts + ((size_t)b * JP + part) * MT_N + t;
-        d[0] = a0;
-        d[CT] = a1;
-        d[2 * CT] = a2;
-        d[3 * CT] = a3;
+        dst[t] = a0;
+        dst[t + CT] = a1;
+        dst[t + 2 * CT] = a2;
+        dst[t + 3 * CT] = a3;
     }
+}
+
+__global__ __launch_bounds__(192) void mt_combine_kernel(const uint32_t *seq, const uint32_t *poly, uint32_t *dst_parts) {
+    const int b = blockIdx.x / JP, part = blockIdx.x % JP;
+    combine_part(seq + (size_t)b * SEQ_PAD + part * PW * 32, poly + part * PW, dst_parts + ((size_t)b * JP + part) * MT_N);
+}
+
+// one radix-16 round: window j * have + b = jump_{j * have chunks}(window b), j = blockIdx.y + 1, for every target < K;
+// polys[j - 1] = t^(j * have * CHUNK) mod phi
+__global__ __launch_bounds__(192) void mt_combine_radix_kernel(const uint32_t *seq, const uint32_t *polys, uint32_t *states,
+                                                               int64_t have, int64_t K) {
+    const int b = blockIdx.x / JP, part = blockIdx.x % JP;
+    const int64_t tgt = (int64_t)(blockIdx.y + 1) * have + b;
+    if (tgt >= K) return;                                                  // block-uniform
+    combine_part(seq + (size_t)b * SEQ_PAD + part * PW * 32, polys + (size_t)blockIdx.y * MT_N + part * PW,
+                 states + ((size_t)tgt * JP + part) * MT_N);
 }
 
 // chunk c (window = states[c]) holds stream words [1 + (c0 + c) * CHUNK, +CHUNK); raw[w - w_lo] for w in [w_lo, w_hi)
@@ -244,6 +257,8 @@ Plan make_plan(int pos_in, int64_t skip, int64_t n) {
 
 }  // namespace
 
+extern "C" int ps_mt19937_chunk_log2(void) { return CHUNK_LOG2; }
+
 extern "C" size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n) {
     if (n < 0 || skip < 0) return 0;
     const Plan p = make_plan(MT_N, skip, n);            // pos only shifts the plan by < 624 words
@@ -255,7 +270,8 @@ extern "C" size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n) {
 
 extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,
                                         uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys,
-                                        int jump_levels, void *workspace, size_t workspace_bytes, ps_stream_t stream) {
+                                        int jump_levels, const uint32_t *radix_polys, int radix_levels, void *workspace,
+                                        size_t workspace_bytes, ps_stream_t stream) {
     if (!state_in || !state_out || !pos_out || n < 0 || skip < 0 || pos_in < 0 || pos_in > MT_N) return PS_EINVAL;
     if (n > 0 && !out) return PS_EINVAL;
     hipStream_t st = ps_stream(stream);
@@ -306,15 +322,30 @@ extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, in
         uint32_t *t = cur; cur = nxt; nxt = t;
     }
     if (hipMemcpyAsync(states, cur, WSZ * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
-    // 3. doubling: states[2^m + r] = jump_{CHUNK * 2^m}(states[r])
-    for (int m = 0; ((int64_t)1 << m) < K; ++m) {
-        const int64_t have = (int64_t)1 << m;
-        const int64_t make = (K - have) < have ? (K - have) : have;
-        hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)make), dim3(256), 0, st, states, seqs);
-        PS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(mt_combine_kernel, dim3((unsigned)(make * JP)), dim3(192), 0, st, seqs,
-                           jump_polys + (size_t)(CHUNK_LOG2 + m) * MT_N, states + (size_t)have * WSZ);
-        PS_CHECK_LAUNCH();
+    // 3. chunk windows: radix-16 rounds (window j * have + r = jump_{j * have chunks}(window r), j = 1..15) when the
+    //    multiplier polynomials are given -- two rounds instead of eight serial expansions for 180 chunks -- else doubling
+    if (radix_polys && radix_levels > 0) {
+        int lvl = 0;
+        for (int64_t have = 1; have < K; have *= 16, ++lvl) {
+            if (lvl >= radix_levels) return PS_EUNSUPPORTED;
+            const int64_t nsrc = (K - have) < have ? (K - have) : have;
+            const int64_t jmax = ((K - 1) / have) < 15 ? ((K - 1) / have) : 15;
+            hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)nsrc), dim3(256), 0, st, states, seqs);
+            PS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(mt_combine_radix_kernel, dim3((unsigned)(nsrc * JP), (unsigned)jmax), dim3(192), 0, st, seqs,
+                               radix_polys + (size_t)lvl * 15 * MT_N, states, have, K);
+            PS_CHECK_LAUNCH();
+        }
+    } else {
+        for (int m = 0; ((int64_t)1 << m) < K; ++m) {
+            const int64_t have = (int64_t)1 << m;
+            const int64_t make = (K - have) < have ? (K - have) : have;
+            hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)make), dim3(256), 0, st, states, seqs);
+            PS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(mt_combine_kernel, dim3((unsigned)(make * JP)), dim3(192), 0, st, seqs,
+                               jump_polys + (size_t)(CHUNK_LOG2 + m) * MT_N, states + (size_t)have * WSZ);
+            PS_CHECK_LAUNCH();
+        }
     }
     // 4. chunks -> raw words; word 0 separately
     hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)K), dim3(256), 0, st, states, p.c0, p.w_lo, p.w_hi, raw);

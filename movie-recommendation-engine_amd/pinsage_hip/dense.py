@@ -159,7 +159,20 @@ def _jump_polys(dev):
     return _jump_polys_dev[key]
 
 
-def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True):
+_radix_polys_dev = {}
+
+
+def _radix_polys(dev):
+    key = str(dev)
+    if key not in _radix_polys_dev:
+        from . import mtjump
+        import numpy as np
+        cl2 = int(nv.lib().ps_mt19937_chunk_log2())
+        _radix_polys_dev[key] = torch.from_numpy(mtjump.radix_polynomials(cl2).view(np.int32)).to(dev).contiguous()
+    return _radix_polys_dev[key]
+
+
+def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=True):
     """n doubles of the process-global numpy legacy stream generated ON THE DEVICE (after skipping `skip`
     doubles); with advance=True the global np.random state is advanced exactly as
     `np.random.random_sample(skip + n)` would (reference utils/random_walk.py:79 draws these one at a time)."""
@@ -173,13 +186,15 @@ def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True):
     pos_out = torch.empty(1, dtype=torch.int32, device=dev)
     out = torch.empty(int(n), dtype=torch.float64, device=dev)
     polys = _jump_polys(dev) if parallel else None
+    rpolys = _radix_polys(dev) if (parallel and radix) else None      # radix=False: windows by doubling
     L = nv.lib()
     wsb = int(L.ps_mt19937_workspace_bytes(nv.i64(int(skip)), nv.i64(int(n)))) if parallel else 0
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if parallel else None
     with torch.cuda.device(dev):
         nv.call("ps_mt19937_random_sample", nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(skip)), nv.i64(int(n)),
                 nv.ptr(out), nv.ptr(st_out), nv.ptr(pos_out), nv.ptr(polys),
-                nv.i32(int(polys.size(0)) if polys is not None else 0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
+                nv.i32(int(polys.size(0)) if polys is not None else 0), nv.ptr(rpolys),
+                nv.i32(int(rpolys.size(0)) if rpolys is not None else 0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
     if advance:
         new_key = st_out.cpu().numpy().view(np.uint32)
         np.random.set_state((name, new_key, int(pos_out.item()), has_gauss, cached))

@@ -240,6 +240,13 @@ def test_device_mt19937_matches_numpy():
     a = dense.mt19937_random_sample(200000, "cuda", advance=False, parallel=False)
     b = dense.mt19937_random_sample(200000, "cuda", advance=False, parallel=True)
     assert torch.equal(a, b)
+    # chunk windows by doubling (no radix-16 table) and by radix-16 rounds agree, incl. > 16 and > 256 chunks
+    for n in (3_000_000, 20_000_000):
+        np.random.seed(21)
+        c = dense.mt19937_random_sample(n, "cuda", advance=False, radix=False)
+        d = dense.mt19937_random_sample(n, "cuda", advance=False, radix=True)
+        assert torch.equal(c, d)
+        assert np.array_equal(d[-1000:].cpu().numpy(), np.random.RandomState(21).random_sample(n)[-1000:])
 
 
 def test_inference_style_flow_unchanged_call_sites():
