@@ -11,13 +11,15 @@
 // accumulator per output (no split-K) -- bit-identical to `acc = fmaf(x[k], w[k], acc)`, which is
 // what the CPU oracle evaluates, so LSH sign decisions are bit-exact.
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN = (WM*TM*32) x (WN*TN*32), K step BK = 32 (BK = 16 was
-// measured 6 % slower: the 64 x 256 tile is register limited to 2 waves per SIMD, not LDS limited).
+// Tiling: WM x WN waves; block tile BM x BN = (WM*TM*32) x (WN*TN*32): 64 x 256 when the epilogue normalises whole
+// rows, 64 x 128 otherwise, 32 x 256 for small shards; K step BK = 32 (BK = 16 was measured 6 % slower: the 64 x 256
+// tile is register limited to 2 waves per SIMD, not LDS limited).
 // LDS image per operand row: [BK/8 groups of 8 k][lane-half h][4] so that the lane (row i, half h)
 // fetches its four k values of one group (k = 8g + 2t + h, t = 0..3) with a single ds_read_b128;
 // row stride BK+4 floats keeps the b128 reads bank-conflict free.  The k-permutation is done
 // in registers while staging (two float4 global loads per row-group), global loads for the next
-// K step are in flight while the current one is multiplied.
+// K step are in flight while the current one is multiplied, and inside a K step the LDS fragments of
+// k-group g+1 are requested before the 16 MFMAs of group g (order pinned with sched_group_barrier).
 #include "ps_common.h"
 
 namespace {

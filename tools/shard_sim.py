@@ -49,10 +49,11 @@ for world in [int(w) for w in a.worlds.split(",")]:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50):
         step()
+    host_ms = (time.perf_counter() - t0) / 50 * 1e3          # time to ENQUEUE a step (python + ctypes + allocator)
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 50 * 1e3
     tm = nv.KernelTimer(); nv.set_timer(tm)
     for _ in range(10):
         step()
     ks = tm.summary(); nv.set_timer(None)
-    print(f"world {world}: {ms:.3f} ms per step (compute only, rank 0 of {world}); "
+    print(f"world {world}: {ms:.3f} ms per step (compute only, rank 0 of {world}; host enqueue {host_ms:.3f} ms); "
           + ", ".join(f"{k[3:]} {v['ms'] / 10:.3f}" for k, v in ks.items()), flush=True)
