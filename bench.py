@@ -114,9 +114,10 @@ def main():
                (synth.ML25M["num_users"], synth.ML25M["num_items"], synth.ML25M["num_ratings"])]
     F_IN, HID, D, LAYERS, W, L, T = 128, 256, a.dim, 2, 100, 2, a.T
     nbits = a.lsh_bits or 2 * D
-    t0 = time.time()
     ei, ew = synth.bipartite_ratings(U, M, R, seed=20240601, device=dev)
-    graph = DeviceGraph(ei, ew, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    graph = DeviceGraph(ei, ew, device=dev)        # CSR + CDF + guide + packed blocks + bucket records (first call: incl. allocations)
     del ei, ew
     torch.cuda.synchronize()
     t_graph = time.time() - t0
