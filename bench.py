@@ -378,7 +378,28 @@ def cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq):
     t_q = time.perf_counter() - t0
     per_item = (t_sample + t_dense + t_enc) / S
     step_s = per_item * M + t_q / Sq * nq
-    return {"value": M / step_s, "unit": "items/s", "cores": threads, "kind": "port",
+    # the same port on ONE core (SURVEY 8d asks for both), on a small slice: 256 start items, 16 queries
+    S1, Q1 = min(256, S), min(16, Sq)
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    l1 = [co.walk_sample(cg, nodes[:S1], T, L, W, philox=(42, call), threads=1)[:3] for call in range(2)]
+    with torch.no_grad():
+        h1 = torch.relu(torch.nn.functional.linear(xs[:S1], P["input_proj.weight"], P["input_proj.bias"]))
+        for i in range(2):
+            hn = torch.from_numpy(co.importance_pool(hfull.numpy(), l1[i][0], l1[i][1], l1[i][2], threads=1))
+            hs = torch.nn.functional.linear(h1, P[f"convs.{i}.lin_self.weight"], P[f"convs.{i}.lin_self.bias"])
+            h1 = torch.nn.functional.normalize(torch.relu(torch.nn.functional.linear(
+                torch.cat([hs, hn], 1), P[f"convs.{i}.lin_update.weight"], P[f"convs.{i}.lin_update.bias"])), dim=1)
+        e1 = torch.nn.functional.normalize(torch.nn.functional.linear(h1, P["output_proj.weight"], P["output_proj.bias"]), dim=1)
+        np.packbits(((e1 @ Ah.t()) >= 0).numpy(), axis=1, bitorder="little")
+    t_item1 = (time.perf_counter() - t0) / S1
+    t0 = time.perf_counter()
+    co.hamming_topk(codes_all[:Q1], codes_all, a.k, threads=1)
+    t_q1 = (time.perf_counter() - t0) / Q1
+    torch.set_num_threads(threads)
+    single = {"value": M / (t_item1 * M + t_q1 * nq), "unit": "items/s", "cores": 1,
+              "sample": f"{S1} start items + {Q1} queries over all {M} codes, scaled to the full step"}
+    return {"value": M / step_s, "unit": "items/s", "cores": threads, "kind": "port", "single_thread": single,
             "sample": (f"the whole step: all {S} start items (sampler x2 layers, pooling, dense, LSH encode) + all {Sq} "
                        f"queries over {M} codes" if S == M and Sq == nq else
                        f"{S} uniformly drawn start items (sampler x2 layers, pooling, dense, LSH encode) + {Sq} queries "
