@@ -143,8 +143,8 @@ def test_importance_pool_golden_and_oracle(golden):
         np.testing.assert_allclose(out.cpu().numpy(), g[f"g2_out_{tag}"], rtol=1e-5, atol=1e-6)
     # larger seeded case vs the C oracle, H = 256 (one 1 KiB row per wave instruction) and odd H
     rs = np.random.RandomState(0)
-    for H in (256, 100, 7):
-        N, B, T = 5000, 3000, 50
+    for H, T in ((256, 50), (100, 50), (7, 50), (64, 150), (256, 64), (32, 65)):   # T > 64: the chunked metadata path
+        N, B = 5000, 3000
         x = rs.standard_normal((N, H)).astype(np.float32)
         idn = rs.randint(0, 2 * N, size=(B, T)).astype(np.int64)   # ~half out of range (user ids dropped)
         cnt = rs.randint(1, 20, size=(B, T)).astype(np.int32)
