@@ -262,7 +262,8 @@ def main():
                     "unit": "GB/s" if kd["bound"] == "hbm" else "TFLOP/s", "frac": kd["frac"],
                     "traffic": traffic.get(dom), "traffic_source": traffic.get("source") if dom in traffic else None,
                     "avg_launch_ms": kd["avg_ms"],
-                    "algorithmic_per_launch": samp_bytes if dom == "ps_walk_sample" else None,
+                    "algorithmic_per_launch": (samp_bytes if dom == "ps_walk_sample" else
+                                               kd["achieved"] * kd["avg_ms"] * 1e-3),      # bytes (hbm) or flops (mfma)
                     "steps_per_launch": (steps0 + steps1) / 2 if dom == "ps_walk_sample" else None,
                     "largest_kernel_by_time": dominant}
         # device kernels behind each C-ABI call (the rows of profiles/*/kernel_stats.csv the timings agree with)
