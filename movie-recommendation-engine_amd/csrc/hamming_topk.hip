@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void hamming_scan_kernel(const uint32_t *__res
             uint32_t tk = __builtin_amdgcn_readlane(tau, qi);
             const uint32_t thi = tk >> shift;
             uint32_t d[G];
+            uint64_t cand[G];
             uint64_t many = 0ull;
 #pragma unroll
             for (int gg = 0; gg < G; ++gg) {
@@ -96,12 +97,14 @@ __global__ __launch_bounds__(256) void hamming_scan_kernel(const uint32_t *__res
                 d[gg] = acc;
                 // ids ascend during the sweep: an item that ties the list's worst distance has a larger id and
                 // can never be admitted, so "distance < bound.distance" is the exact fast-path test
-                many |= __ballot(acc < thi);
+                cand[gg] = __ballot(acc < thi);
+                many |= cand[gg];
             }
             if (many != 0ull) {                                        // rare, wave-uniform
                 uint32_t lk = (lane < kcap) ? L[qi * kcap + lane] : EMPTY_KEY;
 #pragma unroll
                 for (int gg = 0; gg < G; ++gg) {
+                    if (cand[gg] == 0ull) continue;                    // nothing here beat even the bound at entry
                     // candidates of this group against the CURRENT bound (it tightens with every insertion,
                     // so stale candidates drop out of the ballot instead of being visited one by one)
                     const uint32_t key = (d[gg] << shift) | klo[gg];      // out-of-range lanes: all ones = EMPTY_KEY
