@@ -308,3 +308,29 @@ def test_bucket_records_match_their_definition():
                     assert cs[e, i] == cdf[idx] and ks[e, i] == col[idx]
                 else:
                     assert cs[e, i] == 2.0 and ks[e, i] == col[hi - 1]
+
+
+def test_integration_md_ctypes_stub_reproduces_the_golden(golden):
+    """The reference-side ctypes stub printed in INTEGRATION.md (plain C ABI, no accelerator tables) is executed as
+    written and must return the reference's neighbours for a golden case."""
+    import os, re
+    from pinsage_hip import native as nv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = next(b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def batch_sample" in b)
+    code = code.replace('ctypes.CDLL("libpinsage_hip.so")', f'ctypes.CDLL({nv.lib()._name!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    g = golden
+    name = "A" if "A" in G1 else sorted(G1)[0]
+    np.random.seed(int(g[f"g1_{name}_npseed"]))
+    pre = f"g1_{name}_0_"
+    W, L, T = [int(v) for v in g[pre + "WLT"]]
+    graph = ns["build_graph"](torch.from_numpy(g[f"g1_{name}_edge_index"]), torch.from_numpy(g[f"g1_{name}_edge_weights"]))
+    ids, cnt, nvl = ns["batch_sample"](graph, g[pre + "nodes"].tolist(), T, W, L)
+    ids, cnt, nvl = ids.cpu().numpy(), cnt.cpu().numpy(), nvl.cpu().numpy()
+    assert np.array_equal(nvl, g[pre + "nvalid"])
+    for i in range(ids.shape[0]):
+        k = int(nvl[i])
+        assert ids[i, :k].tolist() == g[pre + "ids"][i, :k].tolist()
+        assert (cnt[i, :k] / cnt[i, :k].sum()).tolist() == g[pre + "weights"][i, :k].tolist()
