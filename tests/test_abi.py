@@ -52,3 +52,61 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(d, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def _header_arity():
+    txt = open(os.path.join(ROOT, "include", "pinsage_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    out = {}
+    for name, params in re.findall(r"\b(ps_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        params = params.strip()
+        out[name] = 0 if params in ("", "void") else params.count(",") + 1
+    return out
+
+
+def test_python_call_sites_pass_as_many_arguments_as_the_header_declares():
+    """ctypes calls carry no prototypes: a call site that lags behind a signature change would read garbage.  Every
+    `nv.call("ps_x", ...)` and `lib.ps_x(...)` in the package (and bench/tools) is checked against the header's arity,
+    and so is the C definition in csrc/ (`extern "C" ... ps_x(...)`)."""
+    import ast
+    arity = _header_arity()
+    assert len(arity) >= 25
+    checked = 0
+    roots = [os.path.join(ROOT, "movie-recommendation-engine_amd"), os.path.join(ROOT, "tools"), os.path.join(ROOT, "bench.py"),
+             os.path.join(ROOT, "__graft_entry__.py")]
+    files = []
+    for r in roots:
+        if r.endswith(".py"):
+            files.append(r)
+        else:
+            for d, _, fs in os.walk(r):
+                files += [os.path.join(d, f) for f in fs if f.endswith(".py")]
+    for f in files:
+        tree = ast.parse(open(f).read())
+        for node in ast.walk(tree):
+            if not isinstance(node, ast.Call):
+                continue
+            fn = node.func
+            if isinstance(fn, ast.Attribute) and fn.attr == "call" and node.args and isinstance(node.args[0], ast.Constant) \
+                    and isinstance(node.args[0].value, str) and node.args[0].value in arity:
+                name, n = node.args[0].value, len(node.args) - 1
+            elif isinstance(fn, ast.Attribute) and fn.attr in arity:
+                name, n = fn.attr, len(node.args)
+            else:
+                continue
+            assert not any(isinstance(a, ast.Starred) for a in node.args), (f, name)
+            assert n == arity[name], f"{f}: {name} called with {n} arguments, header declares {arity[name]}"
+            checked += 1
+    assert checked >= 30
+    # the definitions
+    src = ""
+    csrc = os.path.join(ROOT, "movie-recommendation-engine_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith(".hip"):
+            src += re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read())
+    for name, n in arity.items():
+        m = re.search(r'extern\s+"C"\s+[\w\s\*]+?\b' + name + r"\s*\(([^{;]*?)\)\s*\{", src, flags=re.S)
+        assert m, f"{name} has no extern \"C\" definition"
+        params = m.group(1).strip()
+        got = 0 if params in ("", "void") else params.count(",") + 1
+        assert got == n, f"{name}: defined with {got} parameters, declared with {n}"
