@@ -28,8 +28,12 @@ __global__ void prep_keys_kernel(const int64_t *src, int64_t E, uint32_t *keys, 
 // rowptr[v] = first sorted position whose key >= v
 __global__ void rowptr_kernel(const uint32_t *keys, int64_t E, int64_t V, int64_t *rowptr) {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= E; p += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t prev = (p == 0) ? -1 : (int64_t)keys[p - 1];
-        const int64_t cur = (p == E) ? V : (int64_t)keys[p];
+        // keys >= V (an edge whose source id is out of range: the host wrappers reject such input, this is the
+        // last line of defence) are clamped to V, so nothing is ever written past rowptr[V]
+        int64_t prev = (p == 0) ? -1 : (int64_t)keys[p - 1];
+        int64_t cur = (p == E) ? V : (int64_t)keys[p];
+        if (prev > V) prev = V;
+        if (cur > V) cur = V;
         for (int64_t v = prev + 1; v <= cur; ++v) rowptr[v] = p;
     }
 }

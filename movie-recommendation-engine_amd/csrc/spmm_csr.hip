@@ -16,7 +16,7 @@ constexpr int UNROLL = 8;
 
 template <int VEC>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                       const float *__restrict__ val, const float *__restrict__ x, int H,
+                                                       const float *__restrict__ val, const float *__restrict__ x, int64_t N, int H,
                                                        int64_t V, int64_t E, float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int64_t *__restrict
                         const int tl = t < 64 ? t : 0;
                         const int32_t id = (t < kk) ? __builtin_amdgcn_readlane(myid, tl) : -1;
                         wv[u] = (t < kk) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myw), tl)) : 0.f;
-                        const bool ok = id >= 0 && cact;
+                        const bool ok = id >= 0 && (int64_t)id < N && cact;       // a source id outside x is skipped, never read
                         if (VEC == 4) {
                             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
                             if (ok) q = *reinterpret_cast<const float4 *>(x + (int64_t)id * H + cc);
@@ -99,8 +99,8 @@ extern "C" int ps_spmm_csr(const int64_t *rowptr, const int32_t *col, const floa
     const int64_t grid = ps_cdiv(waves, 4);
     if (grid > 0x7fffffff) return PS_EUNSUPPORTED;
     const bool vec4 = (H % 4 == 0) && ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(out)) % 16 == 0);
-    if (vec4) hipLaunchKernelGGL(spmm_csr_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val, x, H, V, E, out);
-    else hipLaunchKernelGGL(spmm_csr_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val, x, H, V, E, out);
+    if (vec4) hipLaunchKernelGGL(spmm_csr_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val, x, N, H, V, E, out);
+    else hipLaunchKernelGGL(spmm_csr_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val, x, N, H, V, E, out);
     PS_CHECK_LAUNCH();
     return PS_OK;
 }

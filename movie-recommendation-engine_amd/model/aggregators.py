@@ -55,8 +55,10 @@ def _pad(neighbors, n_rows, weights=None, mode="weighted"):
 def _pool(features, ids, w, nvalid):
     dev = nv.require_gpu()
     f = (features if features.is_cuda else features.to(dev)).float().contiguous()
-    return sampling.importance_pool(f, ids=torch.from_numpy(ids).to(f.device), wts=torch.from_numpy(w).to(f.device),
-                                    nvalid=torch.from_numpy(nvalid).to(f.device), renorm=False)
+    # sampling.pool keeps the result on the autograd tape when `features` needs a gradient (the reference's
+    # aggregators are plain differentiable torch code, model/aggregators.py:13-91,233-287)
+    return sampling.pool(f, ids=torch.from_numpy(ids).to(f.device), wts=torch.from_numpy(w).to(f.device),
+                         nvalid=torch.from_numpy(nvalid).to(f.device), renorm=False)
 
 
 class MeanAggregator(nn.Module):
@@ -138,7 +140,7 @@ class ImportanceAggregator(nn.Module):
     def forward(self, features, neighbors, importance_weights):
         ids, w, nvalid = _pad(neighbors, int(features.size(0)), importance_weights)
         pooled = _pool(features, ids, w, nvalid)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (pooled.requires_grad or any(p.requires_grad for p in self.parameters())):
             t = F.linear(pooled, self.transform.weight.to(pooled.device), self.transform.bias.to(pooled.device))
         else:
             t = dense.linear(pooled, self.transform.weight.detach().to(pooled.device),

@@ -131,40 +131,6 @@ def _lists_to_padded(x_rows, neighbors, weights):
     return ids, wts, nvalid
 
 
-class _PoolFn(torch.autograd.Function):
-    """ps_importance_pool forward; backward = scatter-add of w_ij * grad_out_i into x rows."""
-
-    @staticmethod
-    def forward(ctx, x, ids, counts, wts, nvalid):
-        out = sampling.importance_pool(x, ids=ids, counts=counts, wts=wts, nvalid=nvalid)
-        ctx.save_for_backward(ids, counts if counts is not None else wts, nvalid)
-        ctx.use_counts = counts is not None
-        ctx.n_rows = x.size(0)
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        ids, cw, nvalid = ctx.saved_tensors
-        N = ctx.n_rows
-        B, T = ids.shape
-        ar = torch.arange(T, device=ids.device)[None, :]
-        valid = (ar < nvalid[:, None]) & (ids >= 0) & (ids < N)
-        if ctx.use_counts:
-            inrow = ar < nvalid[:, None]
-            tot = (cw * inrow).sum(dim=1, keepdim=True).clamp(min=1)
-            w = (cw.double() / tot.double()).float()
-        else:
-            w = cw
-        w = torch.where(valid, w, torch.zeros_like(w))
-        s = w.sum(dim=1, keepdim=True)
-        w = torch.where(s > 0, w / torch.where(s > 0, s, torch.ones_like(s)), w)
-        gx = torch.zeros((N, grad_out.size(1)), dtype=grad_out.dtype, device=grad_out.device)
-        safe = torch.where(valid, ids, torch.zeros_like(ids)).long()
-        for j in range(T):
-            gx.index_add_(0, safe[:, j], grad_out * w[:, j:j + 1])
-        return gx, None, None, None, None
-
-
 def _batch_of(neighbors, weights):
     """The device batch behind a pair of LazyNeighborLists (or a NeighborBatch), else None."""
     if isinstance(neighbors, sampling.NeighborBatch):
@@ -198,10 +164,7 @@ class ImportancePooling(nn.Module):
             wts = torch.from_numpy(wts_h).to(xg.device)
             nvalid = torch.from_numpy(nv_h).to(xg.device)
             counts = None
-        if torch.is_grad_enabled() and xg.requires_grad:
-            out = _PoolFn.apply(xg, ids, counts, wts, nvalid)
-        else:
-            out = sampling.importance_pool(xg, ids=ids, counts=counts, wts=wts, nvalid=nvalid)
+        out = sampling.pool(xg, ids=ids, counts=counts, wts=wts, nvalid=nvalid)     # differentiable w.r.t. x
         return out if x.is_cuda else out.to(x.device)
 
 
@@ -219,8 +182,10 @@ class PinSage(nn.Module):
         self.output_proj = nn.Linear(hidden_channels, out_channels)
 
     # ---- helpers ---------------------------------------------------------------------------
-    def _needs_grad(self):
-        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+    def _needs_grad(self, x=None):
+        """autograd has to see the layers: a parameter or the input features require a gradient"""
+        return torch.is_grad_enabled() and ((x is not None and x.requires_grad) or
+                                            any(p.requires_grad for p in self.parameters()))
 
     def _layer_inputs(self, sampled_neighbors, importance_weights, i):
         per_layer = isinstance(sampled_neighbors, list) and isinstance(importance_weights, list)   # :219
@@ -253,7 +218,7 @@ class PinSage(nn.Module):
             return F.normalize(self.output_proj(h), p=2, dim=1)
 
         # ---- importance-pooled branch (:217-240, :248-249) ----
-        if self._needs_grad():
+        if self._needs_grad(x):
             h = F.relu(self.input_proj(x))
             for i in range(self.num_layers):
                 nb, wt = self._layer_inputs(sampled_neighbors, importance_weights, i)

@@ -86,7 +86,16 @@ class TargetCSR:
     def __init__(self, edge_index, num_nodes):
         dev = nv.require_gpu() if not edge_index.is_cuda else edge_index.device
         ei = edge_index.to(device=dev, dtype=torch.int64)
+        if ei.dim() != 2 or ei.size(0) != 2:
+            raise ValueError("edge_index must have shape [2, num_edges]")
         E, V = int(ei.size(1)), int(num_nodes)
+        if E:
+            # torch / PyG raise on such input (index_add_ / x[src]); the kernels below index rowptr[V+1] and
+            # x[num_nodes] with these ids, so they are checked once here (the result is cached by the caller)
+            lo, hi = int(ei.min().item()), int(ei.max().item())
+            if lo < 0 or hi >= V:
+                raise IndexError(f"edge_index holds node id {lo if lo < 0 else hi}, outside [0, {V}) "
+                                 "(global ids passed with batch-local features?)")
         src, dst = ei[0].contiguous(), ei[1].contiguous()
         self.V, self.E, self.device = V, E, dev
         self.rowptr = torch.empty(V + 1, dtype=torch.int64, device=dev)

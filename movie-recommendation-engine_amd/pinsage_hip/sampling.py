@@ -217,3 +217,49 @@ def importance_pool(x, batch: NeighborBatch = None, ids=None, counts=None, wts=N
                                              nv.ptr(nvalid), nv.i64(B), nv.i32(T), nv.i64(max_idx), nv.i32(int(renorm)),
                                              nv.ptr(out), nv.stream())
     return out
+
+
+class PoolFn(torch.autograd.Function):
+    """Differentiable ps_importance_pool: the forward is the kernel, the backward scatter-adds w_ij * grad_out_i
+    into the feature rows (d out_i / d x_r = sum over the slots j of row i with ids_ij == r of w_ij).  The weights
+    are the ones the kernel used: fp32(count / total) or the given fp32 weights, restricted to the kept slots
+    (j < nvalid, 0 <= id <= max_idx) and, with renorm, divided by their fp32 sum (model/pinsage.py:123-146)."""
+
+    @staticmethod
+    def forward(ctx, x, ids, counts, wts, nvalid, max_idx, renorm):
+        out = importance_pool(x, ids=ids, counts=counts, wts=wts, nvalid=nvalid, max_idx=max_idx, renorm=renorm)
+        ctx.save_for_backward(ids, counts if counts is not None else wts, nvalid)
+        ctx.use_counts = counts is not None
+        ctx.n_rows = int(x.size(0))
+        ctx.max_idx = ctx.n_rows - 1 if max_idx is None else int(max_idx)
+        ctx.renorm = bool(renorm)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ids, cw, nvalid = ctx.saved_tensors
+        N = ctx.n_rows
+        T = ids.size(1)
+        slot = torch.arange(T, device=ids.device)[None, :]
+        inrow = slot < nvalid[:, None]
+        kept = inrow & (ids >= 0) & (ids <= ctx.max_idx)
+        if ctx.use_counts:
+            tot = (cw * inrow).sum(dim=1, keepdim=True).clamp(min=1)
+            w = (cw.double() / tot.double()).float()
+        else:
+            w = cw
+        w = torch.where(kept, w, torch.zeros_like(w))
+        if ctx.renorm:
+            s = w.sum(dim=1, keepdim=True)
+            w = torch.where(s > 0, w / torch.where(s > 0, s, torch.ones_like(s)), w)
+        gx = torch.zeros((N, grad_out.size(1)), dtype=grad_out.dtype, device=grad_out.device)
+        rows = torch.where(kept, ids, torch.zeros_like(ids)).long()
+        gx.index_add_(0, rows.reshape(-1), (grad_out[:, None, :] * w[:, :, None]).reshape(-1, grad_out.size(1)))
+        return gx, None, None, None, None, None, None
+
+
+def pool(x, ids=None, counts=None, wts=None, nvalid=None, max_idx=None, renorm=True):
+    """importance_pool that stays on the autograd tape when `x` needs a gradient."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return PoolFn.apply(x, ids, counts, wts, nvalid, max_idx, renorm)
+    return importance_pool(x, ids=ids, counts=counts, wts=wts, nvalid=nvalid, max_idx=max_idx, renorm=renorm)

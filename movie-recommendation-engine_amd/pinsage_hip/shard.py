@@ -69,28 +69,18 @@ def all_gather_rows(t, chunk, group=None):
     return all_gather_rows_async(t, chunk, group).wait()
 
 
-_FUSED_CACHE = {}
-
-
 def fused_self_update(ops, P, i, H):
     """lin_update(cat[lin_self(h), h_neigh]) = h (Wu1 Ws)^T + h_neigh Wu2^T + (Wu1 bs + bu)  (model/pinsage.py:235-239):
-    the two stacked linear maps on the self path are composed once per forward (a 256^3 GEMM) instead of applied
-    to every row; identical up to fp32 rounding (checked against the reference goldens at 1e-5)."""
+    the two stacked linear maps on the self path are composed (one H^3 GEMM + one GEMV, microseconds) instead of
+    applied to every row; identical up to fp32 rounding (checked against the reference goldens at 1e-5).
+    Nothing is cached here: parameters can be edited in place through `.data` without any version counter moving,
+    so a cache keyed on (address, version) would hand back stale weights.  ShardedPinSage, which owns a parameter
+    snapshot, keeps the composed weights per instance (`refresh_weights`)."""
     Ws, bs = P[f"convs.{i}.lin_self.weight"], P[f"convs.{i}.lin_self.bias"]
     Wu, bu = P[f"convs.{i}.lin_update.weight"], P[f"convs.{i}.lin_update.bias"]
-    # weight preprocessing, reused while the four parameter tensors are unchanged (same storage, same version)
-    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (Ws, bs, Wu, bu)) + (type(ops).__name__,)
-    hit = _FUSED_CACHE.get(key)
-    if hit is not None:
-        return hit[0], hit[1]
-    Wu1 = Wu[:, :H]
-    W1 = ops.linear(Wu1.contiguous(), Ws.t().contiguous(), None)            # [H_out, H_in] = Wu1 @ Ws
-    b1 = ops.linear(bs.reshape(1, -1).contiguous(), Wu1.contiguous(), bu).reshape(-1)   # Wu1 @ bs + bu
-    if len(_FUSED_CACHE) > 64:
-        _FUSED_CACHE.clear()
-    # the entry keeps the four source tensors alive: their storage cannot be freed and handed to another model,
-    # so (address, version) identifies the weights for as long as the entry exists
-    _FUSED_CACHE[key] = (W1, b1, (Ws, bs, Wu, bu))
+    Wu1 = Wu[:, :H].contiguous()
+    W1 = ops.linear(Wu1, Ws.t().contiguous(), None)                          # [H_out, H_in] = Wu1 @ Ws
+    b1 = ops.linear(bs.reshape(1, -1).contiguous(), Wu1, bu).reshape(-1)     # Wu1 @ bs + bu
     return W1, b1
 
 
@@ -138,6 +128,19 @@ class ShardedPinSage:
         self.overlap_sampling = False      # measured: no gain on MI355X (2.69 vs 2.65 ms per pass)
         self.fuse_self = True
         self._streams = {}
+        self._fused = {}                   # layer -> (W1, b1) composed from the snapshot `params`
+
+    def refresh_weights(self, params=None):
+        """Call after changing the parameter tensors (in place or by passing a new dict): drops the composed
+        self-path weights so that the next `embed` recomputes them."""
+        if params is not None:
+            self.P = params
+        self._fused.clear()
+
+    def _fused_layer(self, i, H):
+        if i not in self._fused:
+            self._fused[i] = fused_self_update(self.ops, self.P, i, H)
+        return self._fused[i]
 
     def _side_stream(self, dev):
         key = str(dev)
@@ -191,7 +194,7 @@ class ShardedPinSage:
             H = h.size(1)
             Wu = P[f"convs.{i}.lin_update.weight"]
             if self.fuse_self:
-                W1, b1 = fused_self_update(ops, P, i, H)
+                W1, b1 = self._fused_layer(i, H)
                 a_in = h
             else:
                 a_in = ops.linear(h, P[f"convs.{i}.lin_self.weight"], P[f"convs.{i}.lin_self.bias"])

@@ -94,45 +94,75 @@ class RandomWalkSampler:
         batch = self.sample_batch(nodes, num_neighbors)
         return sampling.LazyNeighborList(batch, "ids"), sampling.LazyNeighborList(batch, "weights")
 
-    # ---- PPR helpers: on the reference's class surface but called by nothing;
-    # kept as host python over the lazily built adjacency list, same arithmetic (:144-229).
+    # ---- PPR helpers: on the reference's class surface (utils/random_walk.py:144-229) but called by nothing
+    # (out of scope for kernels).  Host numpy over the CSR arrays: the reference's in-place
+    # ascending-node sweep is reproduced with a sorted frontier of nodes that hold residual mass, so a sweep costs
+    # O(frontier edges) instead of O(V); pushes to a larger id are seen in the same sweep, to a smaller id in the
+    # next one, exactly as the reference's `for node, res in enumerate(residual)` does.
+    def _ppr_host_csr(self):
+        if getattr(self, "_ppr_csr", None) is None:
+            g = self.graph
+            rowptr = g.rowptr.cpu().numpy()
+            col = g.col.cpu().numpy().astype(np.int64)
+            w = g.wsorted.cpu().numpy()
+            share = np.empty_like(w)
+            for v in np.flatnonzero(np.diff(rowptr)):
+                seg = w[rowptr[v]:rowptr[v + 1]]
+                share[rowptr[v]:rowptr[v + 1]] = seg / np.cumsum(seg)[-1]      # python's left-to-right sum()
+            self._ppr_csr = (rowptr, col, share)
+        return self._ppr_csr
+
+    def _ppr_vector(self, source, size, alpha, sweeps):
+        import heapq
+        rowptr, col, share = self._ppr_host_csr()
+        score = np.zeros(size)
+        mass = np.zeros(size)
+        score[source] = mass[source] = 1.0
+        pending = [source]                                   # nodes with mass > 0 awaiting this sweep
+        for _ in range(sweeps):
+            heap, queued, later = list(pending), set(pending), set()
+            heapq.heapify(heap)
+            while heap:
+                v = heapq.heappop(heap)
+                queued.discard(v)
+                m = mass[v]
+                if not m > 0:
+                    continue
+                score[v] += alpha * m
+                if v + 1 < rowptr.size:
+                    out = (1 - alpha) * m
+                    for e in range(rowptr[v], rowptr[v + 1]):
+                        t = col[e]
+                        mass[t] += out * share[e]
+                        if t > v:
+                            if t not in queued:
+                                queued.add(t)
+                                heapq.heappush(heap, t)
+                        else:
+                            later.add(t)
+                mass[v] = 0
+                later.discard(v)
+            pending = sorted(t for t in later if mass[t] > 0)
+        return score
+
     def compute_ppr_matrix(self, nodes, alpha=0.15, num_iterations=10):
-        if isinstance(nodes, torch.Tensor):
-            nodes = nodes.tolist()
-        n = max(self.graph.V, max(nodes) + 1)
-        out = {}
-        adj = self.adj_list
-        for source in nodes:
-            ppr = np.zeros(n)
-            ppr[source] = 1.0
-            residual = np.zeros(n)
-            residual[source] = 1.0
-            for _ in range(num_iterations):
-                for node, res in enumerate(residual):
-                    if res > 0:
-                        ppr[node] += alpha * res
-                        nbrs = adj[node] if node < len(adj) else []
-                        if nbrs:
-                            push = (1 - alpha) * res
-                            tot = sum(w for _, w in nbrs)
-                            for nb, w in nbrs:
-                                residual[nb] += push * (w / tot)
-                        residual[node] = 0
-            for target, score in enumerate(ppr):
-                if score > 0:
-                    out[(source, target)] = score
-        return out
+        nodes = nodes.tolist() if isinstance(nodes, torch.Tensor) else list(nodes)
+        size = max(self.graph.V, max(nodes) + 1)
+        table = {}
+        for s in nodes:
+            vec = self._ppr_vector(s, size, alpha, num_iterations)
+            table.update({(s, int(t)): float(vec[t]) for t in np.flatnonzero(vec > 0)})
+        return table
 
     def precompute_top_neighbors(self, nodes, num_neighbors=10):
-        ppr = self.compute_ppr_matrix(nodes)
-        top = {}
-        for source in nodes:
-            scores = [(t, s) for (src, t), s in ppr.items() if src == source]
-            scores.sort(key=lambda x: x[1], reverse=True)
-            nb = [t for t, _ in scores[:num_neighbors]]
-            wt = [s for _, s in scores[:num_neighbors]]
-            if wt:
-                tot = sum(wt)
-                wt = [w / tot for w in wt]
-            top[source] = (nb, wt)
-        return top
+        nodes = nodes.tolist() if isinstance(nodes, torch.Tensor) else list(nodes)
+        table = self.compute_ppr_matrix(nodes)
+        per_source = {}
+        for (s, t), v in table.items():                       # dict order = ascending target per source
+            per_source.setdefault(s, []).append((t, v))
+        best = {}
+        for s in nodes:
+            ranked = sorted(per_source.get(s, []), key=lambda tv: -tv[1])[:num_neighbors]   # stable, like reverse=True
+            total = sum(v for _, v in ranked)
+            best[s] = ([t for t, _ in ranked], [v / total for _, v in ranked] if ranked else [])
+        return best

@@ -1,0 +1,127 @@
+"""SURVEY 8f-1 on the GPU: exact L2 search (faiss.IndexFlatL2), the IVF probe restriction (faiss.IndexIVFFlat behind
+WeakANDIndex) and the benchmark harness (reference utils/nearest_neighbors.py:70-254), through the reference-shaped
+classes and the bare `ps_l2_topk` wrapper.
+
+faiss is absent (parity unpinned at that boundary): ids are compared with an fp64 numpy restatement of
+"k smallest by (squared L2, id)", the IVF restriction with the same restatement over the probed lists only, and
+the SYN-25M-size case through size-independent properties (self is nearest, ascending, masked results lie in the
+probed lists)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _probe_bits(probe_lists, nlist):
+    nq = probe_lists.shape[0]
+    bits = np.zeros((nq, (nlist + 31) // 32), dtype=np.uint32)
+    for r in range(nq):
+        for l in probe_lists[r]:
+            bits[r, l >> 5] |= np.uint32(1) << np.uint32(l & 31)
+    return bits
+
+
+def test_l2_topk_and_ivf_masked_search():
+    """ps_l2_topk: exact squared-L2 k-NN (IndexFlatL2, utils/nearest_neighbors.py:89,176) and the probed-lists
+    restriction (IndexIVFFlat, :92) vs a numpy restatement: ids identical (by (distance, id)), distances 1e-4."""
+    from pinsage_hip import dense
+    rs = np.random.RandomState(5)
+    N, D, nq, k, nlist = 4000, 48, 300, 10, 37
+    X = rs.standard_normal((N, D)).astype(np.float32)
+    Q = X[:nq] + 0.05 * rs.standard_normal((nq, D)).astype(np.float32)
+    assign = rs.randint(0, nlist, size=N).astype(np.int32)
+    d2 = ((Q[:, None, :].astype(np.float64) - X[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    order = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    dist, ids = dense.l2_topk(torch.from_numpy(X).cuda(), torch.from_numpy(Q).cuda(), k)
+    assert np.array_equal(ids.cpu().numpy(), order)
+    np.testing.assert_allclose(dist.cpu().numpy(), np.take_along_axis(d2, order, 1), rtol=1e-4, atol=1e-4)
+    probe_lists = np.stack([rs.permutation(nlist)[:5] for _ in range(nq)])          # 5 random lists per query
+    bits = _probe_bits(probe_lists, nlist)
+    vis = (probe_lists[:, :, None] == assign[None, None, :]).any(axis=1)
+    order_m = np.argsort(np.where(vis, d2, np.inf), axis=1, kind="stable")[:, :k]
+    dist, ids = dense.l2_topk(torch.from_numpy(X).cuda(), torch.from_numpy(Q).cuda(), k,
+                              assign=torch.from_numpy(assign).cuda(),
+                              probe=torch.from_numpy(bits.view(np.int32)).cuda())
+    assert np.array_equal(ids.cpu().numpy(), order_m)
+
+
+def test_l2_topk_fewer_visible_items_than_k_pads():
+    """a query whose probed lists hold fewer than k items gets (-1, FLT_MAX) padding, like faiss (:137)."""
+    from pinsage_hip import dense
+    rs = np.random.RandomState(9)
+    X = rs.standard_normal((64, 16)).astype(np.float32)
+    assign = np.arange(64, dtype=np.int32) % 16                                     # 4 items per list
+    bits = _probe_bits(np.array([[3]]), 16)
+    dist, ids = dense.l2_topk(torch.from_numpy(X).cuda(), torch.from_numpy(X[:1]).cuda(), 10,
+                              assign=torch.from_numpy(assign).cuda(), probe=torch.from_numpy(bits.view(np.int32)).cuda())
+    ids = ids.cpu().numpy()[0]
+    assert set(ids[:4].tolist()) == {3, 19, 35, 51} and np.all(ids[4:] == -1)
+    assert np.all(dist.cpu().numpy()[0, 4:] >= 3.0e38)
+
+
+def test_weakand_index_and_benchmark_harness(capsys):
+    from utils.nearest_neighbors import WeakANDIndex, benchmark_search_methods
+    rs = np.random.RandomState(2)
+    centers = rs.standard_normal((40, 32)).astype(np.float32) * 3
+    emb = (centers[rs.randint(0, 40, size=6000)] + 0.3 * rs.standard_normal((6000, 32))).astype(np.float32)
+    idx = WeakANDIndex(32, num_partitions=50)
+    idx.build(emb)
+    assert idx.index.ntotal == 6000 and idx.index.is_trained and idx.quantizer.ntotal == 50
+    d, i = idx.search(emb[:64], k=10)
+    assert d.shape == (64, 10) and i.dtype == np.int64 and d.dtype == np.float32
+    assert idx.index.nprobe == 20                                                   # min(num_partitions, 20), :134
+    assert np.array_equal(i[:, 0], np.arange(64)) and np.all(np.abs(d[:, 0]) < 1e-3)     # self is nearest
+    assert np.all(np.diff(d, axis=1) >= -1e-6)
+    res = benchmark_search_methods(torch.from_numpy(emb), emb[:128], k=10)
+    assert list(res) == ["exact", "lsh", "ivf"]
+    for m in res.values():
+        assert set(m) >= {"distances", "indices", "search_time", "index_size", "method"} and m["index_size"] == 6000
+        assert m["indices"].shape == (128, 10) and m["search_time"] > 0
+    assert [res[m]["method"] for m in res] == ["Exact (Brute Force)", "Locality-Sensitive Hashing", "Weak AND (IVF)"]
+    assert "recall" not in res["exact"]
+    assert res["ivf"]["recall"] > 0.9 and 0.0 < res["lsh"]["recall"] <= 1.0
+    # recall is the reference's definition (:238-246): mean |set(exact_row) & set(method_row)| / k
+    want = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(res["exact"]["indices"], res["lsh"]["indices"])])
+    assert abs(res["lsh"]["recall"] - want) < 1e-12
+    out = capsys.readouterr().out
+    for line in ("Benchmarking exact search...", "Benchmarking lsh search...", "Benchmarking ivf search...",
+                 "Built LSH index with 6000 embeddings", "Built Weak AND index with 6000 embeddings",
+                 "\nBenchmark Results:\n-----------------\nExact (Brute Force):\n  Search time: ",
+                 "  Index size: 6000 vectors", "  Locality-Sensitive Hashing recall@10: ",
+                 "  Weak AND (IVF) recall@10: "):
+        assert line in out, line
+    # a subset of methods without 'exact': no recall is computed (:233), unknown names are skipped
+    res2 = benchmark_search_methods(emb, emb[:8], k=5, methods=["lsh", "nope"])
+    assert list(res2) == ["lsh"] and "recall" not in res2["lsh"] and res2["lsh"]["indices"].shape == (8, 5)
+
+
+def test_ivf_search_full_catalogue_properties():
+    """SYN-25M-sized catalogue (59 047 items, d = 128): WeakANDIndex with the reference's defaults
+    (100 partitions, nprobe 20).  Properties: every query that is an item finds itself first at distance ~0,
+    distances ascend, every hit lies in one of the query's probed lists, and the result equals the exact L2
+    search restricted to those lists."""
+    from pinsage_hip import dense
+    from utils.nearest_neighbors import WeakANDIndex
+    g = torch.Generator().manual_seed(11)
+    M, D, nq, k = 59047, 128, 2048, 11
+    cent = torch.randn(300, D, generator=g)
+    emb = torch.nn.functional.normalize(cent[torch.randint(0, 300, (M,), generator=g)] +
+                                        0.35 * torch.randn(M, D, generator=g), dim=1)
+    idx = WeakANDIndex(D)
+    idx.build(emb)
+    q = emb[:nq]
+    d, i = idx.search(q, k=k)
+    assert d.shape == (nq, k) and np.all(i >= 0)
+    assert np.array_equal(i[:, 0], np.arange(nq)) and np.all(np.abs(d[:, 0]) < 1e-4)
+    assert np.all(np.diff(d, axis=1) >= -1e-6)
+    ivf = idx.index
+    lists = ivf._coarse(q.cuda(), ivf.nprobe).cpu().numpy()                         # [nq, 20]
+    assign = ivf.assign.cpu().numpy()
+    assert np.all((assign[i][:, :, None] == lists[:, None, :]).any(axis=2))         # masked subset of probed lists
+    # against the unrestricted exact search: a hit of the exact search that lives in a probed list must be found
+    de, ie = dense.l2_topk(emb.cuda(), q.cuda(), k)
+    ie = ie.cpu().numpy()
+    inprobe = (assign[ie][:, :, None] == lists[:, None, :]).any(axis=2)
+    for r in range(0, nq, 97):
+        assert set(ie[r][inprobe[r]].tolist()) <= set(i[r].tolist())
