@@ -1,0 +1,544 @@
+// hamming_mfma.hip -- the Hamming k-NN scan of faiss.IndexLSH.search (reference utils/nearest_neighbors.py:47-68)
+// as an EXACT integer contraction on the gfx950 matrix cores.
+//
+// A code of nbits bits is expanded once into nbits int8 values s_j = +1 (bit set) / -1 (bit clear).  Then
+//     dot(q, x) = sum_j s_j(q) s_j(x) = nbits - 2 * hamming(q, x)        (an integer, exact in i32)
+// so the all-pairs distance table is a GEMM, evaluated with v_mfma_i32_32x32x32_i8; zero bytes (padding rows)
+// contribute nothing.  Results are bit-identical to the popcount scan (csrc/hamming_topk.hip): the k smallest by
+// (distance, id), ascending.
+//
+// Sign planes ("fragment order"): for a tile of 32 codes and a 32-bit K step s, one 1 KiB block
+//     planes[(tile * KS + s) * 1024 + lane * 16 + j] = s_{32 s + 16 (lane >> 5) + j}(code 32 tile + (lane & 31))
+// i.e. exactly the 16 bytes lane `lane` feeds to the MFMA as its A (items) or B (queries) operand, so a tile is
+// brought into LDS by global_load_lds_dwordx4 (no registers, lane-linear image, conflict-free ds_read_b128) and a
+// query tile is 16 coalesced dwordx4 loads into registers.  A and B use the same (lane half, byte) -> k map, so the
+// contraction is over matching bits whatever k permutation the hardware applies inside a step.
+//
+// Three passes (all exact; no host synchronisation):
+//   bound   : over the first `sample` items every lane keeps the KM best "minimum of a 16-item group" distances
+//             (branch-free min/max insertion network in registers); the k-th smallest group minimum over a query's
+//             lanes bounds its k-th best distance from above (k distinct groups = k distinct items).
+//   collect : over ALL items, a 32 x 32 tile of dots is 16 MFMAs; lane = query, registers = items, so the admission
+//             test is ONE per-lane threshold: max3 tree + compare, and almost every tile ends there.  Hits are appended
+//             to a lane-private LDS column (no cross-lane traffic, no atomics); a column that fills up is compacted to
+//             its k best and the lane's threshold tightened (exact: ids ascend during the sweep).
+//   merge   : every slice leaves one sorted k-list per query (the two lanes of a query merge theirs in LDS);
+//             slice_merge_kernel merges them by (distance, row): 16 lanes per query, k rounds of a DPP row minimum.
+// One workgroup = 8 waves = 256 queries x one slice of the table; item tiles are shared through a 3-deep LDS ring
+// (counted vmcnt, raw s_barrier); waves 4-7 run their tile epilogue one tile late so that the two waves of a SIMD
+// alternate between the matrix pipe and the VALU instead of meeting at both.
+#include "ps_common.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// experiments only (tools/hm_probe.sh builds variants with -DPS_HM_DEBUG=bits; results are WRONG with any bit set):
+// 1 no tile epilogue, 2 no LDS-DMA, 4 no barrier, 8 no MFMA, 16 no fragment reads
+#ifndef PS_HM_DEBUG
+#define PS_HM_DEBUG 0
+#endif
+constexpr uint32_t EMPTY_KEY = 0xffffffffu;
+constexpr int NBUF = 3;
+constexpr int CAP = 48;                    // slots of a lane's candidate column (LDS); compacted beyond 32
+constexpr int WAVES = 8;
+constexpr int NO_DOT = -(1 << 20);          // "no item": below every real dot (|dot| <= 1024)
+
+// ---- sign planes ------------------------------------------------------------------------------------------------
+// one thread = one 16-byte piece (tile, step, lane)
+__global__ __launch_bounds__(256) void lsh_expand_kernel(const uint32_t *__restrict__ codes, int64_t n, int KS,
+                                                         int64_t pieces, uint4 *__restrict__ planes) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pieces; p += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(p & 63);
+        const int64_t ts = p >> 6;
+        const int s = (int)(ts % KS);
+        const int64_t tile = ts / KS;
+        const int64_t row = tile * 32 + (lane & 31);
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if (row < n) {
+            const uint32_t bits = (codes[row * KS + s] >> (16 * (lane >> 5))) & 0xffffu;
+            // 4 bits -> 4 bytes of +1 (0x01) / -1 (0xff): spread with a 24-bit multiply, then 0xff ^ (b * 0xfe)
+            auto four = [](uint32_t nib) {
+                const uint32_t b = (nib * 0x00204081u) & 0x01010101u;
+                return 0xffffffffu ^ (b * 0xfeu);
+            };
+            o.x = four(bits & 15u); o.y = four((bits >> 4) & 15u); o.z = four((bits >> 8) & 15u); o.w = four(bits >> 12);
+        }
+        planes[p] = o;
+    }
+}
+
+struct HArgs {
+    const unsigned char *qplanes;
+    const unsigned char *dbplanes;
+    int64_t nq, N;
+    int64_t tile_begin, tile_end;   // tiles swept by this launch
+    int64_t tiles_per_slice;
+    int nqb, slices;
+    int k, nbits, shift;
+    int64_t id_offset;
+    const int32_t *thr0;            // collect: per-query admission bound (hamming distance, inclusive)
+    int32_t *bl;                    // bound: [nq][slices * 2][KM] group-minimum distances, ascending
+    int list_base;                  // collect: first output list of this launch (lists of earlier launches precede)
+    int32_t *out_d;                 // collect: [slices][nq][k] distances / table rows (-1 = none), ascending
+    int32_t *out_r;
+};
+
+// LDS-DMA issued from inline asm: hipcc (ROCm 7.2) cannot prove that a ds_read of ring buffer i does not alias the
+// global_load_lds into buffer i+2 and drains vmcnt(0) before every tile's first fragment read when the builtin is
+// used; the asm form is invisible to that pass, and the ring is ordered by hand (counted vmcnt + s_barrier below).
+// No compiler-visible vector-memory operation may be outstanding while these are in flight (its own counted waits
+// would miscount): the sweep is bracketed by explicit vmcnt(0) waits.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void lds_dma16(const void *gptr, uint32_t lds_byte_offset) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte_offset) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+__device__ __forceinline__ int max16(const v16i &a) {
+    int m = max(max(a[0], a[1]), a[2]);
+    m = max(max(m, a[3]), a[4]);  m = max(max(m, a[5]), a[6]);   m = max(max(m, a[7]), a[8]);
+    m = max(max(m, a[9]), a[10]); m = max(max(m, a[11]), a[12]); m = max(max(m, a[13]), a[14]);
+    return max(m, a[15]);
+}
+
+// MODE 0 = bound pass, 1 = collect pass.  One wave = one tile of 32 queries (16 query-fragment registers per 32 bits
+// of code); CAP = slots of a lane's candidate column in LDS (compacted beyond CAP - 16 entries, k <= CAP - 16).
+template <int KS, int MODE, int KM>
+__global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int TILE_BYTES = KS * 1024;
+    constexpr int PPW = (KS + WAVES - 1) / WAVES;          // LDS-DMA pieces per wave and tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const bool late = wv >= 4;                              // SIMD partners are waves w and w + 4
+
+    // XCD-aware block order: blocks b, b + 8, ... share an XCD (and its L2); give them consecutive logical ids so that
+    // an XCD sweeps one or two table slices, not all of them (bijective remap; speed only)
+    const int G = gridDim.x, b = blockIdx.x;
+    const int gq = G >> 3, gr = G & 7, xcd = b & 7;
+    const int logical = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (b >> 3);
+    const int slice = logical / a.nqb, qb = logical - slice * a.nqb;
+    const int64_t qtile = (int64_t)qb * WAVES + wv;
+    const int64_t nqtiles = (a.nq + 31) >> 5;
+    const int64_t q = qtile * 32 + li;
+    const bool q_ok = q < a.nq;
+
+    int64_t t0 = a.tile_begin + (int64_t)slice * a.tiles_per_slice;
+    int64_t t1 = t0 + a.tiles_per_slice;
+    if (t1 > a.tile_end) t1 = a.tile_end;
+    const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
+    const int64_t last_tile = (a.N - 1) >> 5;               // the only tile that can hold padding rows
+    const int last_rows = (int)(a.N - last_tile * 32);
+
+    // query fragments (B operand): 16 bytes per K step, resident for the whole sweep
+    v4i bq[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        bq[s] = v4i{0, 0, 0, 0};
+        if (qtile < nqtiles)
+            bq[s] = *reinterpret_cast<const v4i *>(a.qplanes + ((qtile * KS + s) * 64 + lane) * 16);
+    }
+
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);       // low half of the flat address = LDS offset
+    auto prefetch = [&](int64_t t, int buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wv + WAVES * i;
+            if (p < KS && !(PS_HM_DEBUG & 2)) lds_dma16(a.dbplanes + ((t * KS + p) * 64 + lane) * 16, lds_base + (uint32_t)(buf * KS + p) * 1024u);
+        }
+    };
+
+    // ---- per-lane state ----
+    uint32_t *cand = reinterpret_cast<uint32_t *>(smem + NBUF * TILE_BYTES) + wv * (CAP * 64);   // [slot][lane]
+    int cnt = 0;
+    int thr = 0x7fffffff;                                   // admit iff dot >= thr
+    int best[KM];                                           // bound pass: KM largest group maxima of the dot, descending
+    if (MODE == 1) {
+        if (q_ok) thr = a.nbits - 2 * a.thr0[q];
+    } else {
+#pragma unroll
+        for (int j = 0; j < KM; ++j) best[j] = NO_DOT;
+    }
+
+    // a lane's column -> its k best keys in slots 0..k-1 (ascending), cnt = min(cnt, k); threshold tightened when the
+    // column holds k keys: a later item (larger id) that only ties the k-th distance can never displace it
+    auto compact = [&]() {
+        const int k = a.k;
+        for (int p = 0; p < k; ++p) {
+            uint32_t bestk = (p < cnt) ? cand[p * 64 + lane] : EMPTY_KEY;
+            const uint32_t head = bestk;
+            int bj = p;
+            for (int j = p + 1; j < CAP; ++j) {
+                const uint32_t v = (j < cnt) ? cand[j * 64 + lane] : EMPTY_KEY;
+                if (v < bestk) { bestk = v; bj = j; }
+            }
+            if (p < cnt) {
+                cand[bj * 64 + lane] = head;
+                cand[p * 64 + lane] = bestk;
+            }
+        }
+        cnt = cnt < k ? cnt : k;
+        if (cnt == k) {
+            const int hk = (int)(cand[(k - 1) * 64 + lane] >> a.shift);
+            const int nthr = a.nbits - 2 * hk + 2;
+            thr = nthr > thr ? nthr : thr;
+        }
+    };
+
+    auto epilogue = [&](v16i acc, int i) {
+        const int64_t t = t0 + i;
+        if (t == last_tile && last_rows < 32) {             // wave-uniform: mask the padding rows of the table's end
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((r & 3) + 8 * (r >> 2) + 4 * lh >= last_rows) acc[r] = NO_DOT;
+        }
+        // maximum of the lane's 16 dots as a two-level tree: the four group maxima localise a hit
+        int g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = max(max(max(acc[4 * j], acc[4 * j + 1]), acc[4 * j + 2]), acc[4 * j + 3]);
+        const int m = max(max(max(g[0], g[1]), g[2]), g[3]);
+        if (MODE == 0) {
+            int x = m;
+#pragma unroll
+            for (int j = 0; j < KM; ++j) {
+                const int hi = max(best[j], x);
+                x = min(best[j], x);
+                best[j] = hi;
+            }
+            return;
+        }
+        if (__ballot(m >= thr) == 0ull) return;             // the usual exit
+        const uint32_t base = (uint32_t)i * 32u + 4u * lh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (__ballot(g[j] >= thr) == 0ull) continue;    // rows 8 j + 4 lh + 0..3
+#pragma unroll
+            for (int r = 4 * j; r < 4 * j + 4; ++r) {
+                const bool hit = acc[r] >= thr;
+                if (__ballot(hit) != 0ull) {
+                    if (hit) {
+                        const uint32_t ham = (uint32_t)(a.nbits - acc[r]) >> 1;
+                        cand[cnt * 64 + lane] = (ham << a.shift) | (base + (r & 3) + 8 * (r >> 2));
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        if (__ballot(cnt > CAP - 16) != 0ull) compact();    // room for one more tile (16 rows per lane) is guaranteed
+    };
+
+    // ---- sweep: ring of NBUF item tiles, one barrier per tile ----
+    // query fragments / bounds are in: nothing of the compiler's is in flight from here on.  The builtin form, so that
+    // hipcc's own wait-count pass knows it (an asm wait is invisible to it and it would wait vmcnt(0) again at the
+    // first use of a query fragment INSIDE the loop, i.e. drain the ring on every tile)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j)
+        if (j < nt) prefetch(t0 + j, j);
+    v16i acc_prev;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_prev[r] = NO_DOT;
+    int buf = 0;
+    for (int i = 0; i < nt; ++i) {
+        // own pieces of tile i have landed (younger tiles' may be in flight); after the barrier everybody's have, and
+        // everybody has finished reading tile i-1, whose buffer the next LDS-DMA overwrites
+        const int younger = nt - 1 - i;
+        if (younger >= NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NBUF - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(PS_HM_DEBUG & 4)) __builtin_amdgcn_s_barrier();
+        if (i + NBUF - 1 < nt) prefetch(t0 + i + NBUF - 1, buf >= 1 ? buf - 1 : NBUF - 1);
+        // all K steps' item fragments are requested at once (KS ds_read_b128 in flight; with the compiler's own 2-deep
+        // interleave the LDS round trip sat between every MFMA pair); a late wave's previous-tile epilogue runs under
+        // that latency
+        const unsigned char *tb = smem + buf * TILE_BYTES + lane * 16;
+        v4i av[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            av[s] = (PS_HM_DEBUG & 16) ? v4i{i, s, lane, 1} : *reinterpret_cast<const v4i *>(tb + s * 1024);
+        __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);
+        if (late && i > 0 && !(PS_HM_DEBUG & 1)) epilogue(acc_prev, i - 1);
+        v16i acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (PS_HM_DEBUG & 8) acc[s & 15] += av[s][0] ^ bq[s][1];
+            else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[s], bq[s], acc, 0, 0, 0);
+        }
+        if (PS_HM_DEBUG & 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_prev[r] ^= acc[r];      // keep the work alive
+        } else if (!late) epilogue(acc, i);
+        else acc_prev = acc;
+        buf = buf + 1 < NBUF ? buf + 1 : 0;
+    }
+    if (late && nt > 0 && !(PS_HM_DEBUG & 1)) epilogue(acc_prev, nt - 1);
+    if (PS_HM_DEBUG & 1) { if (max16(acc_prev) == 12345678) cnt = 1; }
+
+    // ---- results ----
+    if (MODE == 0) {
+        if (q_ok) {
+            int32_t *dst = a.bl + ((int64_t)q * (a.slices * 2) + slice * 2 + lh) * KM;
+#pragma unroll
+            for (int j = 0; j < KM; ++j) dst[j] = best[j] == NO_DOT ? 0x7fffffff : (a.nbits - best[j]) >> 1;
+        }
+        return;
+    }
+    // the two lanes of a query (rows 4 lh + ... of every tile) merge their sorted columns: one k-list per (slice, query)
+    compact();
+    ps_wave_lds_sync();
+    const int cnt_hi = __shfl(cnt, li + 32, 64);
+    if (q_ok && lh == 0) {
+        const uint32_t idmask = (1u << a.shift) - 1u;
+        const int64_t o = ((int64_t)(a.list_base + slice) * a.nq + q) * a.k;
+        int ia = 0, ib = 0;
+        for (int p = 0; p < a.k; ++p) {
+            const uint32_t ka = ia < cnt ? cand[ia * 64 + lane] : EMPTY_KEY;
+            const uint32_t kb = ib < cnt_hi ? cand[ib * 64 + lane + 32] : EMPTY_KEY;
+            const uint32_t key = ka < kb ? ka : kb;
+            if (ka < kb) ++ia; else ++ib;
+            const bool has = key != EMPTY_KEY;
+            a.out_d[o + p] = has ? (int32_t)(key >> a.shift) : 0x7fffffff;
+            a.out_r[o + p] = has ? (int32_t)((key & idmask) + (uint32_t)(t0 * 32)) : -1;
+        }
+    }
+}
+
+// Final merge of the per-slice lists: 16 lanes per query, lane j = the head of slice j's sorted list; k rounds of
+// "row minimum of the 64-bit keys distance << 32 | table row" (4 DPP exchange steps, no LDS), the winner advances.
+// One wave = 4 queries.  ids = row + id_offset; missing entries (-1, INT32_MAX) like faiss.
+__device__ __forceinline__ uint64_t row_min_u64(uint64_t v) {
+#define PS_STEP(ctrl)                                                                                         \
+    {                                                                                                         \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, ctrl, 0xf, 0xf, true); \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), ctrl, 0xf, 0xf, true); \
+        const uint64_t o = ((uint64_t)hi << 32) | lo;                                                         \
+        v = o < v ? o : v;                                                                                    \
+    }
+    PS_STEP(0xB1) PS_STEP(0x4E) PS_STEP(0x141) PS_STEP(0x140)
+#undef PS_STEP
+    return v;
+}
+
+__global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t *__restrict__ din, const int32_t *__restrict__ rin,
+                                                          int P, int64_t nq, int k, int64_t id_offset,
+                                                          int32_t *__restrict__ dout, int64_t *__restrict__ iout) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t q = wave * 4 + (lane >> 4);
+    const bool mine = q < nq && sub < P;
+    const int64_t base = mine ? ((int64_t)sub * nq + q) * k : 0;
+    constexpr uint64_t NONE = ~0ull;
+    auto head = [&](int ptr) -> uint64_t {
+        if (!mine || ptr >= k) return NONE;
+        const int32_t r = rin[base + ptr];
+        return r < 0 ? NONE : ((uint64_t)(uint32_t)din[base + ptr] << 32) | (uint32_t)r;
+    };
+    int ptr = 0;
+    uint64_t key = head(0);
+    for (int r = 0; r < k; ++r) {
+        const uint64_t m = row_min_u64(key);
+        if (sub == 0 && q < nq) {
+            dout[q * k + r] = m == NONE ? 0x7fffffff : (int32_t)(m >> 32);
+            iout[q * k + r] = m == NONE ? -1 : (int64_t)(uint32_t)m + id_offset;
+        }
+        if (key == m && m != NONE) key = head(++ptr);
+    }
+}
+
+// one wave per query: thr0 = the k-th smallest of the query's group minima (all bound lists), or nbits (admit
+// everything) when the sample held fewer than k groups
+__global__ __launch_bounds__(256) void bound_select_kernel(const int32_t *__restrict__ bl, int64_t nq, int nvals, int k,
+                                                           int nbits, int32_t *__restrict__ thr0) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t q = wave; q < nq; q += nw) {
+        int v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int c = r * 64 + lane;
+            v[r] = c < nvals ? bl[q * nvals + c] : 0x7fffffff;
+        }
+        int lo = 0, hi = nbits;                              // smallest d with #(v <= d) >= k, else nbits
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) c += __popcll(__ballot(v[r] <= mid));
+            if (c >= k) hi = mid; else lo = mid + 1;
+        }
+        if (lane == 0) thr0[q] = lo;
+    }
+}
+
+int key_shift_bits(int nbits) {
+    int dbits = 1;
+    while ((1 << (dbits - 1)) < nbits) ++dbits;
+    return 32 - dbits;
+}
+
+struct Plan {
+    bool ok;
+    int KS, nqb, slices, bslices, shift, km;
+    int64_t tiles, tiles_per_slice, sample_tiles, btiles_per_slice;
+    size_t off_thr, off_bl, off_i, off_d, total;
+};
+
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
+    Plan p{};
+    p.ok = false;
+    if (cs % 4 != 0) return p;
+    p.KS = cs / 4;
+    if (!(p.KS == 1 || p.KS == 2 || p.KS == 4 || p.KS == 8 || p.KS == 16)) return p;
+    if (k <= 0 || k > 32) return p;
+    if (nq < 64 || N < 4096) return p;                    // small problems: the popcount kernel has no tile padding
+    p.km = k <= 16 ? 16 : 32;
+    p.shift = key_shift_bits(cs * 8);
+    p.tiles = (N + 31) >> 5;
+    const int64_t nqt = (nq + 31) >> 5;
+    p.nqb = (int)((nqt + WAVES - 1) / WAVES);
+    const int slots = env_int("PS_HAMMING_MFMA_SLOTS", 256);      // one 8-wave workgroup per CU
+    int64_t s = slots / p.nqb;
+    if (s < 1) s = 1;
+    if (s > 16) s = 16;
+    while (s > 1 && p.tiles / s < 32) --s;                 // a slice is at least 32 tiles (1024 items)
+    const int64_t cap_tiles = ((int64_t)1 << p.shift) >> 5;
+    if (p.tiles > s * cap_tiles) s = (p.tiles + cap_tiles - 1) / cap_tiles;   // slice-local ids must fit under the distance bits
+    p.tiles_per_slice = (p.tiles + s - 1) / s;
+    p.slices = (int)((p.tiles + p.tiles_per_slice - 1) / p.tiles_per_slice);
+    if (p.slices > 16) return p;                           // merge fan-in: one list per slice, 16 lanes per query
+    // bound pass: 1/5 of the table (measured on MI355X, 10 000 x 59 047 x 512 bit: 5 % 0.67 ms, 10 % 0.48, 20 % 0.44,
+    // 30 % 0.45: every candidate that passes the bound costs ~180 SIMD cycles in the collect pass), at least 16 groups
+    // per lane so that a lane's list can hold KM real minima
+    int64_t st = env_int("PS_HAMMING_MFMA_SAMPLE_TILES", 0);
+    if (st <= 0) st = p.tiles / 5;
+    if (st < 64) st = 64;
+    if (st > p.tiles) st = p.tiles;
+    int64_t bs = slots / p.nqb;
+    if (bs < 1) bs = 1;
+    if (bs > 8) bs = 8;                                    // <= 16 lists of KM <= 32 values per query (bound_select: 512)
+    while (bs > 1 && st / bs < 16) --bs;
+    p.btiles_per_slice = (st + bs - 1) / bs;
+    p.bslices = (int)((st + p.btiles_per_slice - 1) / p.btiles_per_slice);
+    p.sample_tiles = st;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    p.off_thr = take((size_t)nq * sizeof(int32_t));
+    p.off_bl = take((size_t)nq * p.bslices * 2 * p.km * sizeof(int32_t));
+    p.off_i = take((size_t)p.slices * nq * k * sizeof(int32_t));
+    p.off_d = take((size_t)p.slices * nq * k * sizeof(int32_t));
+    p.total = off + 256;
+    p.ok = true;
+    return p;
+}
+
+// dynamic LDS beyond 64 KiB has to be allowed per kernel (idempotent; the only process-wide state this file touches)
+template <typename K>
+bool allow_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) ==
+           hipSuccess;
+}
+
+template <int KS>
+int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t *bl, int64_t nq) {
+    const size_t tiles_lds = (size_t)NBUF * KS * 1024;
+    const size_t lds = tiles_lds + (size_t)WAVES * CAP * 64 * sizeof(uint32_t);
+    static const bool lds_ok = allow_lds(hamming_mfma_kernel<KS, 0, 16>, 160 * 1024) &&
+                               allow_lds(hamming_mfma_kernel<KS, 0, 32>, 160 * 1024) &&
+                               allow_lds(hamming_mfma_kernel<KS, 1, 16>, 160 * 1024);
+    if (!lds_ok) return PS_ELAUNCH;
+    a.nqb = p.nqb;
+    // bound
+    HArgs b = a;
+    b.tile_begin = 0; b.tile_end = p.sample_tiles; b.tiles_per_slice = p.btiles_per_slice; b.slices = p.bslices; b.bl = bl;
+    const unsigned gb = (unsigned)(p.nqb * p.bslices);
+    if (p.km == 16) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 16>), dim3(gb), dim3(512), tiles_lds, st, b);
+    else hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 32>), dim3(gb), dim3(512), tiles_lds, st, b);
+    PS_CHECK_LAUNCH();
+    int64_t gs = ps_cdiv(nq, 4);
+    if (gs > 4096) gs = 4096;
+    hipLaunchKernelGGL(bound_select_kernel, dim3((unsigned)gs), dim3(256), 0, st, bl, nq, p.bslices * 2 * p.km, a.k, a.nbits, thr0);
+    PS_CHECK_LAUNCH();
+    // collect
+    a.tile_begin = 0; a.tile_end = p.tiles; a.tiles_per_slice = p.tiles_per_slice; a.slices = p.slices; a.thr0 = thr0;
+    a.list_base = 0;
+    const unsigned gc = (unsigned)(p.nqb * p.slices);
+    hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 16>), dim3(gc), dim3(512), lds, st, a);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ps_lsh_planes_bytes(int64_t n, int cs) {
+    if (n <= 0 || cs <= 0 || cs % 4 != 0) return 0;
+    return (size_t)((n + 31) / 32) * (size_t)(cs / 4) * 1024;
+}
+
+extern "C" int ps_lsh_expand(const uint8_t *codes, int64_t n, int cs, void *planes, ps_stream_t stream) {
+    if (n < 0 || cs <= 0) return PS_EINVAL;
+    if (cs % 4 != 0) return PS_EUNSUPPORTED;
+    if (n == 0) return PS_OK;
+    if (!codes || !planes || reinterpret_cast<size_t>(codes) % 4 != 0 || reinterpret_cast<size_t>(planes) % 16 != 0)
+        return PS_EINVAL;
+    const int KS = cs / 4;
+    const int64_t pieces = ((n + 31) / 32) * KS * 64;
+    int64_t grid = ps_cdiv(pieces, 256);
+    if (grid > 256 * 64) grid = 256 * 64;
+    hipLaunchKernelGGL(lsh_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ps_stream(stream),
+                       reinterpret_cast<const uint32_t *>(codes), n, KS, pieces, reinterpret_cast<uint4 *>(planes));
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+extern "C" size_t ps_hamming_topk_mfma_workspace_bytes(int64_t nq, int64_t N, int cs, int k) {
+    const Plan p = make_plan(nq, N, cs, k);
+    return p.ok ? p.total : 0;                                // 0 = shape not served by the MFMA path
+}
+
+extern "C" int ps_hamming_topk_mfma(const void *qplanes, int64_t nq, const void *dbplanes, int64_t N, int cs, int k,
+                                    int64_t id_offset, int32_t *dist, int64_t *ids, void *workspace,
+                                    size_t workspace_bytes, ps_stream_t stream) {
+    if (nq < 0 || N < 0 || cs <= 0 || k <= 0) return PS_EINVAL;
+    const Plan p = make_plan(nq, N, cs, k);
+    if (!p.ok) return PS_EUNSUPPORTED;
+    if (!qplanes || !dbplanes || !dist || !ids) return PS_EINVAL;
+    if ((reinterpret_cast<size_t>(qplanes) | reinterpret_cast<size_t>(dbplanes)) % 16 != 0) return PS_EINVAL;
+    if (!workspace || workspace_bytes < p.total) return PS_EWORKSPACE;
+    char *base = reinterpret_cast<char *>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
+    int32_t *thr0 = reinterpret_cast<int32_t *>(base + p.off_thr);
+    int32_t *bl = reinterpret_cast<int32_t *>(base + p.off_bl);
+    int32_t *cr = reinterpret_cast<int32_t *>(base + p.off_i);
+    int32_t *cd = reinterpret_cast<int32_t *>(base + p.off_d);
+    hipStream_t st = ps_stream(stream);
+    HArgs a{};
+    a.qplanes = reinterpret_cast<const unsigned char *>(qplanes);
+    a.dbplanes = reinterpret_cast<const unsigned char *>(dbplanes);
+    if (N >= ((int64_t)1 << 31)) return PS_EUNSUPPORTED;     // table rows travel as int32 between the passes
+    a.nq = nq; a.N = N; a.k = k; a.nbits = cs * 8; a.shift = p.shift; a.id_offset = id_offset;
+    a.out_d = cd; a.out_r = cr;
+    int rc;
+    switch (p.KS) {
+        case 1: rc = launch_passes<1>(p, a, st, thr0, bl, nq); break;
+        case 2: rc = launch_passes<2>(p, a, st, thr0, bl, nq); break;
+        case 4: rc = launch_passes<4>(p, a, st, thr0, bl, nq); break;
+        case 8: rc = launch_passes<8>(p, a, st, thr0, bl, nq); break;
+        case 16: rc = launch_passes<16>(p, a, st, thr0, bl, nq); break;
+        default: return PS_EUNSUPPORTED;
+    }
+    if (rc != PS_OK) return rc;
+    hipLaunchKernelGGL(slice_merge_kernel, dim3((unsigned)ps_cdiv(nq, 16)), dim3(256), 0, st, cd, cr, p.slices, nq, k, id_offset,
+                       dist, ids);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}

@@ -79,8 +79,30 @@ def lsh_encode(x, A):
     return codes
 
 
-def hamming_topk(qcodes, codes, k, id_offset=0):
-    """-> (dist int32[nq,k], ids int64[nq,k]): k smallest by (distance, id), ascending."""
+def lsh_expand(codes):
+    """Sign planes of a code table (uint8 [n, cs] -> +1/-1 bytes in MFMA fragment order, see csrc/hamming_mfma.hip);
+    None when the code size is not a multiple of 4 bytes."""
+    _require_cuda(codes)
+    codes = codes.contiguous()
+    n, cs = int(codes.size(0)), int(codes.size(1))
+    nb = int(nv.lib().ps_lsh_planes_bytes(nv.i64(n), nv.i32(cs)))
+    if nb == 0:
+        return None
+    planes = torch.empty(nb, dtype=torch.uint8, device=codes.device)
+    with torch.cuda.device(codes.device):
+        nv.call("ps_lsh_expand", nv.ptr(codes), nv.i64(n), nv.i32(cs), nv.ptr(planes), nv.stream())
+    return planes
+
+
+def hamming_mfma_supported(nq, N, cs, k):
+    return int(nv.lib().ps_hamming_topk_mfma_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(cs), nv.i32(k))) > 0
+
+
+def hamming_topk(qcodes, codes, k, id_offset=0, planes=None, use_mfma=True):
+    """-> (dist int32[nq,k], ids int64[nq,k]): k smallest by (distance, id), ascending.
+    `planes` = lsh_expand(codes), kept by the index: the scan then runs as an exact int8 MFMA contraction when the
+    shape is served (ps_hamming_topk_mfma); otherwise, and for `use_mfma=False`, the popcount kernel runs.  Both
+    return the same bits."""
     _require_cuda(qcodes, codes)
     qcodes = qcodes.contiguous()
     codes = codes.contiguous()
@@ -89,6 +111,16 @@ def hamming_topk(qcodes, codes, k, id_offset=0):
     dist = torch.empty((nq, k), dtype=torch.int32, device=qcodes.device)
     ids = torch.empty((nq, k), dtype=torch.int64, device=qcodes.device)
     L = nv.lib()
+    if use_mfma and planes is not None:
+        wsb = int(L.ps_hamming_topk_mfma_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(cs), nv.i32(k)))
+        if wsb > 0:
+            qplanes = lsh_expand(qcodes)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=qcodes.device)
+            with torch.cuda.device(qcodes.device):
+                nv.call("ps_hamming_topk_mfma", nv.ptr(qplanes), nv.i64(nq), nv.ptr(planes), nv.i64(N), nv.i32(cs),
+                        nv.i32(k), nv.i64(id_offset), nv.ptr(dist), nv.ptr(ids), nv.ptr(ws), nv.C.c_size_t(wsb),
+                        nv.stream())
+            return dist, ids
     wsb = int(L.ps_hamming_topk_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(cs), nv.i32(k)))
     ws = torch.empty(wsb, dtype=torch.uint8, device=qcodes.device)
     with torch.cuda.device(qcodes.device):

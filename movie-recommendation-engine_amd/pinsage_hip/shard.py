@@ -105,8 +105,11 @@ class HipOps:
     def lsh_encode(self, x, A):
         return dense.lsh_encode(x, A)
 
-    def hamming_topk(self, q, codes, k, id_offset):
-        return dense.hamming_topk(q, codes, k, id_offset=id_offset)
+    def lsh_planes(self, codes):
+        return dense.lsh_expand(codes)
+
+    def hamming_topk(self, q, codes, k, id_offset, planes=None):
+        return dense.hamming_topk(q, codes, k, id_offset=id_offset, planes=planes)
 
     def topk_merge(self, d, i):
         return dense.topk_merge(d, i)
@@ -212,6 +215,8 @@ class ShardedPinSage:
     def build_index(self, emb_local, A):
         self.A = A
         self.codes = self.ops.lsh_encode(emb_local, A)
+        # sign planes of the local code shard for the int8-MFMA scan (backends without them scan the packed codes)
+        self.planes = self.ops.lsh_planes(self.codes) if hasattr(self.ops, "lsh_planes") else None
         return self.codes
 
     def search(self, q_local, k):
@@ -221,7 +226,10 @@ class ShardedPinSage:
         qc = ops.lsh_encode(q_local, self.A)
         nq_local = qc.size(0)
         qc_all = all_gather_rows(qc, nq_local, self.group)
-        d, i = ops.hamming_topk(qc_all, self.codes, k, self.lo)
+        if getattr(self, "planes", None) is not None:
+            d, i = ops.hamming_topk(qc_all, self.codes, k, self.lo, planes=self.planes)
+        else:
+            d, i = ops.hamming_topk(qc_all, self.codes, k, self.lo)
         if self.world == 1:
             return d, i
         nq = qc_all.size(0)

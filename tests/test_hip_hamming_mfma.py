@@ -1,0 +1,128 @@
+"""The int8-MFMA Hamming scan (csrc/hamming_mfma.hip: ps_lsh_expand + ps_hamming_topk_mfma) vs the C oracle's
+restatement of faiss' hammings_knn_hc (reference utils/nearest_neighbors.py:47-68) and vs the popcount kernel:
+(distance, id) lists must be bit-identical -- same distances, same ids, same tie order, same padding.
+
+Edge cases the domain has: a ragged last tile (N % 32 != 0), nq % 32 != 0 and nq % 256 != 0, exact duplicates
+(distance ties broken by id), a table of identical codes (EVERY distance ties: the lane-private candidate columns
+overflow and are compacted over and over), clustered codes, k = 1 / 16 / 17 / 32 (both column capacities), every
+served code size, id offsets (shards)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _codes(rs, n, cs, kind):
+    if kind == "random":
+        return rs.randint(0, 256, size=(n, cs)).astype(np.uint8)
+    if kind == "clustered":                                     # 40 centres, a few flipped bits each: many small distances
+        cent = rs.randint(0, 256, size=(40, cs)).astype(np.uint8)
+        c = cent[rs.randint(0, 40, size=n)].copy()
+        flips = rs.randint(0, cs * 8, size=(n, 3))
+        for j in range(3):
+            c[np.arange(n), flips[:, j] >> 3] ^= (1 << (flips[:, j] & 7)).astype(np.uint8)
+        return c
+    if kind == "same":
+        return np.tile(rs.randint(0, 256, size=(1, cs)).astype(np.uint8), (n, 1))
+    raise ValueError(kind)
+
+
+def test_sign_planes_layout():
+    """planes[(tile*KS + s)*1024 + lane*16 + j] = +1/-1 for bit 32 s + 16 (lane >> 5) + j of code 32 tile + (lane & 31);
+    rows past the end are zero bytes (they contribute nothing to a dot product)."""
+    from pinsage_hip import dense
+    rs = np.random.RandomState(0)
+    n, cs = 77, 16
+    codes = rs.randint(0, 256, size=(n, cs)).astype(np.uint8)
+    pl = dense.lsh_expand(torch.from_numpy(codes).cuda()).cpu().numpy().view(np.int8)
+    KS, tiles = cs // 4, (n + 31) // 32
+    assert pl.size == tiles * KS * 1024
+    pl = pl.reshape(tiles, KS, 64, 16)
+    bits = np.unpackbits(codes, axis=1, bitorder="little")      # bit j of the code, LSB-first bytes (faiss)
+    want = np.zeros((tiles * 32, cs * 8), dtype=np.int8)
+    want[:n] = bits.astype(np.int8) * 2 - 1
+    want = want.reshape(tiles, 32, KS, 2, 16).transpose(0, 2, 3, 1, 4).reshape(tiles, KS, 64, 16)
+    assert np.array_equal(pl, want)
+
+
+@pytest.mark.parametrize("cs,kind,N,nq,k", [
+    (64, "random", 4096 + 17, 300, 11),
+    (64, "clustered", 6000, 257, 10),
+    (32, "random", 5000, 64, 1),
+    (32, "clustered", 4100, 500, 16),
+    (16, "random", 8000, 333, 17),
+    (8, "random", 4500, 100, 32),
+    (4, "random", 4200, 96, 5),
+    (64, "same", 4100, 70, 11),
+    (32, "same", 5000, 64, 20),
+])
+def test_mfma_scan_matches_oracle_and_popcount(cs, kind, N, nq, k):
+    from oracle import c_oracle as co
+    from pinsage_hip import dense
+    rs = np.random.RandomState(cs * 1000 + N + k)
+    codes = _codes(rs, N, cs, kind)
+    codes[100] = codes[7]; codes[N - 1] = codes[7]; codes[N - 33] = codes[7]      # duplicates incl. the ragged tail
+    q = codes[rs.permutation(N)[:nq]].copy()
+    q[0] = codes[7]
+    q[1:nq // 2] ^= rs.randint(0, 256, size=(nq // 2 - 1, cs)).astype(np.uint8) & rs.randint(0, 2, size=(nq // 2 - 1, cs)).astype(np.uint8)
+    ct, qt = torch.from_numpy(codes).cuda(), torch.from_numpy(q).cuda()
+    assert dense.hamming_mfma_supported(nq, N, cs, k)
+    planes = dense.lsh_expand(ct)
+    dm, im = dense.hamming_topk(qt, ct, k, planes=planes)
+    dv, iv = dense.hamming_topk(qt, ct, k, use_mfma=False)
+    assert torch.equal(dm, dv) and torch.equal(im, iv)
+    rd, ri = co.hamming_topk(q, codes, k, threads=8)
+    assert np.array_equal(im.cpu().numpy(), ri)
+    assert np.array_equal(dm.cpu().numpy().astype(np.float32), rd)
+    if kind != "same" and k >= 3:
+        assert im[0, :3].tolist() == sorted([7, 100, N - 33, N - 1])[:3] and int(dm[0, 0]) == 0
+    # shards: id offsets + merge reproduce the single-table answer
+    cut = (N // 2) // 32 * 32 + 5
+    if cut >= 4096 or N - cut >= 4096:
+        parts = []
+        for lo, hi in ((0, cut), (cut, N)):
+            sub = ct[lo:hi].contiguous()
+            parts.append(dense.hamming_topk(qt, sub, k, id_offset=lo, planes=dense.lsh_expand(sub)))
+        dmm, imm = dense.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+        assert torch.equal(dmm, dm) and torch.equal(imm, im)
+
+
+def test_mfma_unsupported_shapes_fall_back():
+    """k > 32, small tables and few queries are served by the popcount kernel; the wrapper must say so, not fail"""
+    from pinsage_hip import dense
+    assert not dense.hamming_mfma_supported(1000, 10000, 64, 33)
+    assert not dense.hamming_mfma_supported(1000, 3000, 64, 11)
+    assert not dense.hamming_mfma_supported(10, 10000, 64, 11)
+    assert not dense.hamming_mfma_supported(1000, 10000, 128, 11)
+    rs = np.random.RandomState(3)
+    codes = torch.from_numpy(rs.randint(0, 256, size=(5000, 32)).astype(np.uint8)).cuda()
+    planes = dense.lsh_expand(codes)
+    d1, i1 = dense.hamming_topk(codes[:100], codes, 50, planes=planes)            # k = 50 -> popcount kernel
+    d2, i2 = dense.hamming_topk(codes[:100], codes, 50)
+    assert torch.equal(d1, d2) and torch.equal(i1, i2)
+
+
+@pytest.mark.parametrize("nbits,d,k", [(512, 256, 11), (256, 128, 11), (512, 256, 10)])
+def test_mfma_scan_full_catalogue_equals_popcount(nbits, d, k):
+    """BASELINE configs 2 / 3 sizes: 10 000 queries x 59 047 items through LSHIndex; the MFMA path (default) and the
+    popcount kernel return the same bits; self is the nearest item at distance 0; distances ascend; ids are the
+    (distance, id) order."""
+    from utils.nearest_neighbors import LSHIndex
+    g = torch.Generator().manual_seed(nbits + k)
+    M, nq = 59047, 10000
+    cent = torch.randn(500, d, generator=g)
+    emb = torch.nn.functional.normalize(cent[torch.randint(0, 500, (M,), generator=g)] +
+                                        0.5 * torch.randn(M, d, generator=g), dim=1).cuda()
+    idx = LSHIndex(d, nbits, 16)
+    idx.build(emb)
+    assert idx.index.planes is not None
+    q = emb[torch.randperm(M, generator=g)[:nq].cuda()]
+    dm, im = idx.search_device(q, k)
+    idx.index.use_mfma = False
+    dv, iv = idx.search_device(q, k)
+    assert torch.equal(dm, dv) and torch.equal(im, iv)
+    assert int((dm[:, 0] != 0).sum()) == 0
+    assert bool((dm[:, 1:] >= dm[:, :-1]).all())
+    tie = dm[:, 1:] == dm[:, :-1]
+    assert bool((im[:, 1:][tie] > im[:, :-1][tie]).all())
