@@ -31,9 +31,16 @@ import torch.distributed as dist
 
 HBM_PEAK = 8.0e12          # B/s, spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, v_mfma_f32_32x32x2_f32
-# Hamming scan: one v_xor + one v_bcnt per 32-bit word and 64 pairs; measured issue rates 0.75 / 0.50
-# wave-instr/ns/SIMD (profiles/r01_valu_rate_ubench.txt) -> 256 B / 3.33 ns * 1024 SIMDs of logical code bytes
-VALU_POPCNT_PEAK = 78.7e12
+# v_mfma_i32_32x32x32_i8: 2 x the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores) = 65 536 ops per 32 cycles per
+# SIMD; 1024 SIMDs at 2.4 GHz
+MFMA_I8_PEAK = 1024 * 65536 / 32 * 2.4e9
+# popcount scan (fallback path): SURVEY 8(d)'s bound, wave64 VALU at 2 clocks per instruction (SIMD-32): one v_xor + one
+# v_bcnt per 32-bit word and 64 pairs = 256 B of logical code bytes per 4 clocks per SIMD
+VALU_POPCNT_PEAK = 1024 * 256 / 4 * 2.4e9
+
+# BASELINE.json configs that fit one GPU (configs[1], configs[2]); the default run is the configuration the metric is
+# quoted on (d = 256, T = 10, 512-bit codes)
+PRESETS = {2: dict(dim=128, T=10, lsh_bits=256), 3: dict(dim=256, T=50, lsh_bits=512)}
 
 
 def parse():
@@ -47,10 +54,18 @@ def parse():
     ap.add_argument("--queries", type=int, default=10000)
     ap.add_argument("--k", type=int, default=11, help="num_recommendations + 1 (inference.py:110)")
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of ML-25M (tests)")
-    ap.add_argument("--rng", default="philox", choices=["philox", "numpy"])
+    ap.add_argument("--rng", default="numpy", choices=["philox", "numpy"],
+                    help="numpy = the reference's global np.random MT19937 stream (bit-exact ids; the mode the goldens pin); "
+                         "philox = counter-based, shard-count invariant, no stream generation")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3],
+                    help="BASELINE.json config preset: 2 = d128/T10/256-bit, 3 = d256/T50/512-bit (the rocprof roofline run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="start items timed on the CPU (0 = the whole catalogue)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config:
+        for k, v in PRESETS[a.config].items():
+            setattr(a, k, v)
+    return a
 
 
 def ceil_log2p1(d):
@@ -238,6 +253,8 @@ def main():
                           "ms_per_step": round(k["ms"] / a.steps, 4), "bound": bound, "achieved": ach,
                           "peak": unit_peak, "frac": ach / unit_peak}
 
+        # the fused launch samples LAYERS rounds per start node: per-launch work = the sum over the layers
+        add("ps_walk_sample_layers", "hbm", sb0 + sb1, HBM_PEAK)
         add("ps_walk_sample", "hbm", samp_bytes, HBM_PEAK)
         add("ps_importance_pool", "hbm", pool_bytes, HBM_PEAK)
         if "ps_linear" in ksum:
@@ -245,33 +262,42 @@ def main():
         if "ps_lsh_encode" in ksum:
             rows = (n_loc + nq_local) / 2.0                      # two launches per step: index + queries
             add("ps_lsh_encode", "mfma", enc_flops * rows, MFMA_F32_PEAK)
-        # Hamming scan: the 3.8 MB table is L2 resident; the bound is the VALU popcount rate on the logical
-        # code bytes compared (nq * N * nbits/8), not HBM
+        # Hamming scan as an exact int8 contraction: 2 * nq * N * nbits integer ops (dot = nbits - 2 * hamming); the C-ABI
+        # call covers the bound pass (1/5 of the table again), the collect pass and the slice merge
+        add("ps_hamming_topk_mfma", "mfma", 2.0 * nq * n_loc * nbits, MFMA_I8_PEAK)
+        # popcount fallback (shapes the MFMA path does not serve): VALU bound on the logical code bytes
         add("ps_hamming_topk", "valu", float(nq) * n_loc * (nbits // 8), VALU_POPCNT_PEAK)
+        if "ps_mt19937_random_sample" in ksum:                    # numpy-stream mode: 8 B written per uniform
+            add("ps_mt19937_random_sample", "hbm", 8.0 * (steps0 + steps1), HBM_PEAK)
         try:
             traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
         except Exception:
             traffic = {}
-        dominant = max(kern, key=lambda n: kern[n]["ms_per_step"])
-        # `roofline`: the kernel with the largest time per step among the HBM- / MFMA-bound ones (the Hamming
-        # scan is neither: it is listed under `kernels` against its measured VALU bound)
-        dom = max((n for n in kern if kern[n]["bound"] in ("hbm", "mfma")), key=lambda n: kern[n]["ms_per_step"])
+        # `roofline`: the C-ABI call with the largest time per step, whatever bounds it
+        dom = max(kern, key=lambda n: kern[n]["ms_per_step"])
         kd = kern[dom]
-        div = 1e9 if kd["bound"] == "hbm" else 1e12
+        div = 1e9 if kd["bound"] in ("hbm", "valu") else 1e12
+        unit = {"hbm": "GB/s", "valu": "GB/s", "mfma": "TFLOP/s"}[kd["bound"]]
+        if dom == "ps_hamming_topk_mfma":
+            unit = "TOP/s"
         roofline = {"kernel": dom, "bound": kd["bound"], "achieved": kd["achieved"] / div, "peak": kd["peak"] / div,
-                    "unit": "GB/s" if kd["bound"] == "hbm" else "TFLOP/s", "frac": kd["frac"],
+                    "unit": unit, "frac": kd["frac"],
                     "traffic": traffic.get(dom), "traffic_source": traffic.get("source") if dom in traffic else None,
-                    "avg_launch_ms": kd["avg_ms"],
-                    "algorithmic_per_launch": (samp_bytes if dom == "ps_walk_sample" else
-                                               kd["achieved"] * kd["avg_ms"] * 1e-3),      # bytes (hbm) or flops (mfma)
-                    "steps_per_launch": (steps0 + steps1) / 2 if dom == "ps_walk_sample" else None,
-                    "largest_kernel_by_time": dominant}
+                    "avg_launch_ms": kd["avg_ms"], "algorithmic_per_launch": kd["achieved"] * kd["avg_ms"] * 1e-3,
+                    "note": {"ps_hamming_topk_mfma": "exact int8 MFMA contraction; peak = dense i8 (2 x bf16 per clock at 2.4 GHz); "
+                                                     "the call includes the bound pass over 1/5 of the table, counted as overhead",
+                             "ps_walk_sample_layers": "algorithmic bytes per SURVEY 8(d) (rowptr pair + log2(deg) CDF probes + col "
+                                                      "[+ uniform] per taken step), both layers of a start node in one launch"}.get(dom)}
         # device kernels behind each C-ABI call (the rows of profiles/*/kernel_stats.csv the timings agree with)
-        symbols = {"ps_walk_sample": ["walk_sample_kernel<4>"], "ps_importance_pool": ["importance_pool_kernel<4>"],
+        symbols = {"ps_walk_sample_layers": ["walk_sample_kernel<4>"], "ps_walk_sample": ["walk_sample_kernel<4>"],
+                   "ps_importance_pool": ["importance_pool_kernel<4>"],
                    "ps_linear": ["gemm_f32_kernel<2,2,1,2,32,0,true> (input_proj: no row norm, 64x128 tiles)",
                                  "gemm_f32_kernel<1,4,2,2,32,0,true> (layers + output_proj: fused L2 norm, 64x256 tiles)"],
                    "ps_lsh_encode": ["gemm_f32_kernel<2,2,1,2,32,1,true>"],
-                   "ps_hamming_topk": ["hamming_scan_kernel<16,4>", "topk_merge_kernel"]}
+                   "ps_hamming_topk_mfma": ["hamming_mfma_kernel<KS,0,16> (bound)", "bound_select_kernel",
+                                            "hamming_mfma_kernel<KS,1,16> (collect)", "slice_merge_kernel"],
+                   "ps_hamming_topk": ["hamming_scan_kernel<16,4>", "topk_rank_merge_kernel"],
+                   "ps_mt19937_random_sample": ["mt_* (jump-ahead windows + chunk generators)"]}
         for n, k in kern.items():
             k["device_kernels"] = symbols.get(n, [])
         if "ps_importance_pool" in kern:
@@ -282,14 +308,19 @@ def main():
             k["achieved"] = k["achieved"] / div
             k["peak"] = k["peak"] / div
             k["unit"] = "TFLOP/s" if k["bound"] == "mfma" else "GB/s"
+        if "ps_hamming_topk_mfma" in kern:
+            kern["ps_hamming_topk_mfma"]["unit"] = "TOP/s"
 
         out = {
             "metric": "item embeddings/sec + top-K ANN queries/sec, ML-25M d=256, 1/2/4/8 GPU",
             "value": value, "unit": "items/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64 cdf / f32 features / u32 codes", "data": "synthetic",
+            "dtype": "f64 cdf / f32 features / i8 sign planes (exact integer Hamming)", "data": "synthetic",
             "config": {"workload": f"SYN-25M (ML-25M-shaped: U={U} M={M} R={R}), F=128 H=256 d={D}, 2 GCN layers, "
-                                   f"W=100 L=2 T={T}, LSH {nbits}-bit, {nq} queries K={a.k}, rng={a.rng}",
+                                   f"W=100 L=2 T={T}, LSH {nbits}-bit, {nq} queries K={a.k}, rng={a.rng}"
+                                   + (" (the reference's np.random MT19937 stream generated on device: neighbour ids bit-exact with "
+                                      "the reference CPU path)" if a.rng == "numpy" else " (counter-based, shard invariant)")
+                                   + (f", BASELINE config {a.config}" if a.config else ""),
                        "global_items": M, "queries": nq, "parallelism": f"item-shard x{world}"},
             "embeddings_per_s": M / (phase_ms["embed"] / a.steps * 1e-3),
             "index_items_per_s": M / (phase_ms["index"] / a.steps * 1e-3),
@@ -302,38 +333,43 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq)
             out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        if world == 1 and a.rng == "philox":
-            out["numpy_stream_mode"] = numpy_mode_probe(graph, model, pipe, x_loc, T, W, L, M, dev)
+        if world == 1:
+            out["other_rng_mode"] = other_mode_probe(a, graph, params, LAYERS, M, x_loc, A, T, W, L, nq_local)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def numpy_mode_probe(graph, model, pipe, x_loc, T, W, L, M, dev):
-    """The numpy-compatible RNG mode (bit-exact with the reference's np.random stream), with the MT19937
-    stream generated on the device (GF(2) jump-ahead, 2^16-word chunks) inside the timed region."""
-    from pinsage_hip import dense, sampling
+def other_mode_probe(a, graph, params, LAYERS, M, x_loc, A, T, W, L, nq_local):
+    """The same step in the RNG mode that is NOT the headline (philox when the run is rng=numpy and vice versa),
+    timed over a few steps after a short warm-up: both modes are reported by every run."""
+    from pinsage_hip.shard import ShardedPinSage
     from utils.random_walk import RandomWalkSampler
-    smp = RandomWalkSampler.from_graph(graph, L, W, rng="numpy")
-    nodes = torch.arange(M, dtype=torch.int64, device=dev)
-    ts = []
-    for _ in range(3):
-        np.random.seed(42)
+    other = "philox" if a.rng == "numpy" else "numpy"
+    smp = RandomWalkSampler.from_graph(graph, L, W, rng=other, seed=42)
+    pipe = ShardedPinSage(params, LAYERS, smp, M)
+
+    def step():
+        if other == "numpy":
+            np.random.seed(42)
+        emb = pipe.embed(x_loc, T)
+        pipe.build_index(emb, A)
+        return pipe.search(emb[:nq_local], a.k)
+
+    with torch.no_grad():
+        for _ in range(5):
+            step()
         torch.cuda.synchronize()
+        n = max(5, min(20, a.steps))
         t0 = time.perf_counter()
-        with torch.no_grad():
-            lists = []
-            for _l in range(2):
-                u = dense.mt19937_random_sample(M * W * L, dev)
-                b = sampling.walk_sample(graph, nodes, T, W, L, rng="numpy", uniforms=u)
-                lists.append((sampling.LazyNeighborList(b, "ids"), sampling.LazyNeighborList(b, "weights")))
-            model(x_loc, None, [l[0] for l in lists], [l[1] for l in lists])
+        for _ in range(n):
+            step()
         torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
-    return {"embeddings_per_s": M / min(ts), "ms": min(ts) * 1e3,
-            "note": "reference-exact RNG mode: np.random MT19937 stream generated on device (jump-ahead chunks) + "
-                    "sampler + pooled forward; global np.random state handed back"}
+        dt = (time.perf_counter() - t0) / n
+    return {"rng": other, "value": M / dt, "unit": "items/s", "ms_per_step": dt * 1e3,
+            "note": "same step (embed + index + query) with the other RNG mode; philox = counter-based uniforms computed in "
+                    "the walk kernel, numpy = the reference's global MT19937 stream generated on the device"}
 
 
 def cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq):

@@ -103,6 +103,20 @@ int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf,
                    const void *packed, const void *buckets, int32_t *ids, int32_t *counts, int32_t *nvalid,
                    ps_stream_t stream);
 
+/* PinSage.get_embeddings draws one fresh sample per GCN layer for the SAME start nodes (model/pinsage.py:271-275:
+ * `for layer in range(num_layers): batch_sample_neighbors(nodes, num_neighbors)`).  This entry point runs `layers`
+ * consecutive samples of every start node in one wave: the start row is brought into LDS once and the per-node fixed
+ * chain (start id -> row bounds -> row) is paid once.  Results are exactly those of `layers` ps_walk_sample calls:
+ * PS_RNG_PHILOX uses call, call + 1, ...; PS_RNG_STREAM reads layer r's uniforms at r * layer_stride + uoff[i] + w*L + s
+ * (layer_stride = the uniforms one whole batch consumes = total[0] of ps_uniform_offsets, i.e. the reference's order:
+ * all of layer 0's draws, then all of layer 1's).  ids/counts int32[layers, B, T], nvalid int32[layers, B]. */
+int ps_walk_sample_layers(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
+                          const int64_t *starts, int64_t B, int W, int L, int T,
+                          int rng_mode, const double *uniforms, const int64_t *uoff, int64_t layer_stride,
+                          uint64_t seed, uint32_t call, const uint32_t *nodeinfo, const int32_t *guide,
+                          const void *packed, const void *buckets, int layers,
+                          int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream);
+
 /* _single_walk (utils/random_walk.py:52-83), batched: one walk of L steps per start node, one lane
  * per walk.  paths int32[B,L]: the visited nodes after the start (-1 once the walk hit a sink).
  * PS_RNG_STREAM: walk i, step s reads uniforms[uoff[i] + s]; PS_RNG_PHILOX: philox(seed; node, w, s/2, call)
@@ -124,8 +138,8 @@ int ps_uniform_offsets(const int64_t *rowptr, int64_t V, const int64_t *starts, 
  * jump_polys uint32[jump_levels, 624] (row m = t^(2^m) mod phi over GF(2), from pinsage_hip/mtjump.py) enables
  * the parallel path (2^c-word chunks, c = ps_mt19937_chunk_log2(), generated by independent workgroups, windows by
  * jump-ahead); with NULL polynomials / workspace a single workgroup generates the stream serially (skip must be 0).
- * radix_polys uint32[radix_levels, 15, 624] (entry (i, j-1) = t^(j * 2^(c + 4i)) mod phi, optional): the chunk windows
- * are then produced in radix-16 rounds instead of by doubling. */
+ * radix_polys uint32[radix_levels, 31, 624] (entry (i, j-1) = t^(j * 2^(c + 5i)) mod phi, optional): the chunk windows
+ * are then produced in radix-32 rounds instead of by doubling. */
 int ps_mt19937_chunk_log2(void);
 size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n);
 int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,

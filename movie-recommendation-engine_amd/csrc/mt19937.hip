@@ -176,7 +176,7 @@ __global__ __launch_bounds__(192) void mt_combine_kernel(const uint32_t *seq, co
     combine_part(seq + (size_t)b * SEQ_PAD + part * PW * 32, poly + part * PW, dst_parts + ((size_t)b * JP + part) * MT_N);
 }
 
-// one radix-16 round: window j * have + b = jump_{j * have chunks}(window b), j = blockIdx.y + 1, for every target < K;
+// one radix-32 round: window j * have + b = jump_{j * have chunks}(window b), j = blockIdx.y + 1, for every target < K;
 // polys[j - 1] = t^(j * have * CHUNK) mod phi
 __global__ __launch_bounds__(192) void mt_combine_radix_kernel(const uint32_t *seq, const uint32_t *polys, uint32_t *states,
                                                                int64_t have, int64_t K) {
@@ -322,18 +322,18 @@ extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, in
         uint32_t *t = cur; cur = nxt; nxt = t;
     }
     if (hipMemcpyAsync(states, cur, WSZ * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
-    // 3. chunk windows: radix-16 rounds (window j * have + r = jump_{j * have chunks}(window r), j = 1..15) when the
+    // 3. chunk windows: radix-32 rounds (window j * have + r = jump_{j * have chunks}(window r), j = 1..31) when the
     //    multiplier polynomials are given -- two rounds instead of eight serial expansions for 180 chunks -- else doubling
     if (radix_polys && radix_levels > 0) {
         int lvl = 0;
-        for (int64_t have = 1; have < K; have *= 16, ++lvl) {
+        for (int64_t have = 1; have < K; have *= 32, ++lvl) {
             if (lvl >= radix_levels) return PS_EUNSUPPORTED;
             const int64_t nsrc = (K - have) < have ? (K - have) : have;
-            const int64_t jmax = ((K - 1) / have) < 15 ? ((K - 1) / have) : 15;
+            const int64_t jmax = ((K - 1) / have) < 31 ? ((K - 1) / have) : 31;
             hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)nsrc), dim3(256), 0, st, states, seqs);
             PS_CHECK_LAUNCH();
             hipLaunchKernelGGL(mt_combine_radix_kernel, dim3((unsigned)(nsrc * JP), (unsigned)jmax), dim3(192), 0, st, seqs,
-                               radix_polys + (size_t)lvl * 15 * MT_N, states, have, K);
+                               radix_polys + (size_t)lvl * 31 * MT_N, states, have, K);
             PS_CHECK_LAUNCH();
         }
     } else {

@@ -39,6 +39,8 @@ struct WalkArgs {
     int stage_blocks;   // start rows of at most this many 128-byte blocks are searched in LDS
     int region_words;   // LDS words shared by the staged row (walk phase) and the hash table (count phase)
     const unsigned char *buckets;   // 64-byte bucket records (ps_bucket_build) or NULL
+    int rounds;                     // independent samples per start node (one per GCN layer), all in one wave
+    int64_t round_stride;           // PS_RNG_STREAM: uniforms of round r start at r * round_stride + uoff[i]
 };
 
 // One Philox4x32-10 block = the uniforms of two consecutive steps of a walk: counter (node, walk, step / 2, call);
@@ -297,9 +299,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
     const int wv = threadIdx.x >> 6;
     const int HS = 1 << a.hs_log2;
     const int P = a.W * a.L;
-    const int per_wave = NP * 64 + a.region_words + BITMAP_WORDS;
-    int32_t *posb = smem + wv * per_wave;
-    int32_t *hkey = posb + NP * 64;
+    const int R = a.rounds;
+    const int per_wave = R * NP * 64 + a.region_words + BITMAP_WORDS;
+    int32_t *posb_all = smem + wv * per_wave;               // visited ids of every round, [round][walk * L + step]
+    int32_t *hkey = posb_all + R * NP * 64;
     int32_t *hcnt = hkey + HS;
     int32_t *hfirst = hcnt + HS;
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(hkey + a.region_words);
@@ -314,18 +317,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             lo0 = (eidx_t)uniform_i64(a.rowptr[s]);
             hi0 = (eidx_t)uniform_i64(a.rowptr[s + 1]);
         }
-        int32_t *oid = a.ids + i * a.T;
-        int32_t *ocn = a.counts + i * a.T;
         if (hi0 == lo0) {   // isolated start node -> ([], [])  (random_walk.py:109-110)
-            for (int t = lane; t < a.T; t += 64) { oid[t] = -1; ocn[t] = 0; }
-            if (lane == 0) a.nvalid[i] = 0;
+            for (int r = 0; r < R; ++r) {
+                for (int t = lane; t < a.T; t += 64) { a.ids[(r * a.B + i) * a.T + t] = -1; a.counts[(r * a.B + i) * a.T + t] = 0; }
+                if (lane == 0) a.nvalid[r * a.B + i] = 0;
+            }
             continue;
         }
-        const int64_t ubase = (a.rng_mode == PS_RNG_STREAM) ? uniform_i64(a.uoff[i]) : 0;
+        const int64_t ubase0 = (a.rng_mode == PS_RNG_STREAM) ? uniform_i64(a.uoff[i]) : 0;
 
-        // ---------------- walk phase --------------------------------------------------
-#pragma unroll
-        for (int j = 0; j < NP; ++j) posb[j * 64 + lane] = -1;
+        // ---------------- walk phase: all rounds, the start row is staged once ----------
+        for (int j = lane; j < R * NP * 64; j += 64) posb_all[j] = -1;
         // the start row's packed blocks -> LDS (over the hash-table area, which is initialised after the walks)
         const eidx_t b0 = lo0 >> 3, nblk = ((hi0 - 1) >> 3) - b0 + 1;
         const bool staged = a.packed != nullptr && nblk <= (eidx_t)a.stage_blocks;
@@ -338,6 +340,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         ps_wave_lds_sync();
         // two walks per lane (w and w + 64) advance in lockstep: their CDF probes are independent, so
         // every iteration of the search loop keeps two loads in flight per lane.
+        for (int rd = 0; rd < R; ++rd) {
+        int32_t *posb = posb_all + rd * NP * 64;
+        const int64_t ubase = ubase0 + rd * a.round_stride;
+        const uint32_t call = a.call + (uint32_t)rd;
         for (int w0 = 0; w0 < a.W; w0 += 128) {
             const int wA = w0 + lane, wB = w0 + 64 + lane;
             const bool actA = wA < a.W, actB = wB < a.W;
@@ -357,8 +363,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                     if (aliveA) uA = a.uniforms[ubase + (int64_t)wA * a.L + st];
                     if (aliveB) uB = a.uniforms[ubase + (int64_t)wB * a.L + st];
                 } else if ((st & 1) == 0) {
-                    philox_uniform2(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wA, (uint32_t)(st >> 1), a.call, uA, uA1);
-                    philox_uniform2(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wB, (uint32_t)(st >> 1), a.call, uB, uB1);
+                    philox_uniform2(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wA, (uint32_t)(st >> 1), call, uA, uA1);
+                    philox_uniform2(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wB, (uint32_t)(st >> 1), call, uB, uB1);
                 } else {
                     uA = uA1;
                     uB = uB1;
@@ -373,6 +379,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                 if (actB) posb[wB * a.L + st] = nB;
             }
         }
+        }
+        for (int rd = 0; rd < R; ++rd) {
+        const int32_t *posb = posb_all + rd * NP * 64;
+        int32_t *oid = a.ids + ((int64_t)rd * a.B + i) * a.T;
+        int32_t *ocn = a.counts + ((int64_t)rd * a.B + i) * a.T;
         // ---------------- count phase -------------------------------------------------
         for (int h = lane; h < HS; h += 64) { hkey[h] = -1; hcnt[h] = 0; hfirst[h] = 0x7fffffff; }
         for (int b = lane; b < nbw; b += 64) bitmap[b] = 0u;
@@ -428,8 +439,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         }
         const int nv = emitted < a.T ? emitted : a.T;
         for (int t = nv + lane; t < a.T; t += 64) { oid[t] = -1; ocn[t] = 0; }
-        if (lane == 0) a.nvalid[i] = nv;
+        if (lane == 0) a.nvalid[(int64_t)rd * a.B + i] = nv;
         ps_wave_lds_sync();
+        }
     }
 }
 
@@ -554,12 +566,13 @@ __global__ void graph_stats_kernel(const int64_t *rowptr, const int32_t *col, in
 
 }  // namespace
 
-extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
+static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                               const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
                               const double *uniforms, const int64_t *uoff, uint64_t seed, uint32_t call,
                               const uint32_t *nodeinfo, const int32_t *guide, const void *packed, const void *buckets,
-                              int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream) {
-    if (B < 0 || W <= 0 || L <= 0 || T <= 0 || V < 0) return PS_EINVAL;
+                              int rounds, int64_t round_stride, int32_t *ids, int32_t *counts, int32_t *nvalid,
+                              ps_stream_t stream) {
+    if (B < 0 || W <= 0 || L <= 0 || T <= 0 || V < 0 || rounds <= 0 || rounds > 8 || round_stride < 0) return PS_EINVAL;
     if (B == 0) return PS_OK;
     if (!rowptr || !col || !cdf || !starts || !ids || !counts || !nvalid) return PS_EINVAL;
     if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX) return PS_EINVAL;
@@ -569,22 +582,23 @@ extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const d
     if (buckets && (!nodeinfo || reinterpret_cast<size_t>(buckets) % 64 != 0)) return PS_EINVAL;
     const int64_t P = (int64_t)W * L;
     if (P > 1024) return PS_EUNSUPPORTED;
-    if (B == 0) return PS_OK;
     int np = 1;
     while (np * 64 < P) np <<= 1;
     int hs_log2 = 6;
     while ((1 << hs_log2) * 4 < 5 * P) ++hs_log2;      // table >= 1.25 P slots (load factor <= 0.8)
     WalkArgs a{rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff,
-               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0, reinterpret_cast<const unsigned char *>(buckets)};
+               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0, reinterpret_cast<const unsigned char *>(buckets),
+               rounds, round_stride};
     // LDS budget: the kernel holds 24 waves per CU by registers; 160 KB / 24 leaves ~6.6 KB per wave, and whatever
-    // the hash table does not need of that lets longer start rows be staged.
+    // the position buffers and the hash table do not need of that lets longer start rows be staged.
     const int hash_words = 3 * (1 << hs_log2);
-    int region_words = (6656 / 4) - np * 64 - BITMAP_WORDS;
+    int region_words = (6656 / 4) - rounds * np * 64 - BITMAP_WORDS;
     if (region_words < hash_words) region_words = hash_words;
     region_words &= ~31;                                    // whole 128-byte blocks
     a.region_words = region_words;
     a.stage_blocks = packed ? region_words / 32 : 0;
-    const size_t lds = (size_t)WAVES_PER_BLOCK * (np * 64 + region_words + BITMAP_WORDS) * sizeof(int32_t);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * (rounds * np * 64 + region_words + BITMAP_WORDS) * sizeof(int32_t);
+    if (lds > 64 * 1024) return PS_EUNSUPPORTED;
     int64_t grid = ps_cdiv(B, WAVES_PER_BLOCK);
     if (grid > (int64_t)1 << 30) grid = (int64_t)1 << 30;
     hipStream_t st = ps_stream(stream);
@@ -598,6 +612,25 @@ extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const d
     }
     PS_CHECK_LAUNCH();
     return PS_OK;
+}
+
+extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
+                              const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
+                              const double *uniforms, const int64_t *uoff, uint64_t seed, uint32_t call,
+                              const uint32_t *nodeinfo, const int32_t *guide, const void *packed, const void *buckets,
+                              int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream) {
+    return walk_sample_launch(rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff, seed, call, nodeinfo, guide,
+                              packed, buckets, 1, 0, ids, counts, nvalid, stream);
+}
+
+extern "C" int ps_walk_sample_layers(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
+                                     const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
+                                     const double *uniforms, const int64_t *uoff, int64_t layer_stride, uint64_t seed,
+                                     uint32_t call, const uint32_t *nodeinfo, const int32_t *guide, const void *packed,
+                                     const void *buckets, int layers, int32_t *ids, int32_t *counts, int32_t *nvalid,
+                                     ps_stream_t stream) {
+    return walk_sample_launch(rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff, seed, call, nodeinfo, guide,
+                              packed, buckets, layers, layer_stride, ids, counts, nvalid, stream);
 }
 
 extern "C" int ps_walk_paths(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,

@@ -253,6 +253,12 @@ class PinSage(nn.Module):
         """reference model/pinsage.py:253-280: fresh neighbour samples per layer, then the pooled forward."""
         all_neighbors, all_weights = [], []
         n = x.size(0)
+        if hasattr(random_walk_sampler, "sample_batches"):
+            # every layer's fresh sample of nodes 0..n-1 in one launch, same draws in the same order (:271-275)
+            for batch in random_walk_sampler.sample_batches(range(n), num_neighbors, self.num_layers):
+                all_neighbors.append(sampling.LazyNeighborList(batch, "ids"))
+                all_weights.append(sampling.LazyNeighborList(batch, "weights"))
+            return self.forward(x, edge_index=None, sampled_neighbors=all_neighbors, importance_weights=all_weights)
         for _ in range(self.num_layers):
             if hasattr(random_walk_sampler, "sample_batch"):
                 nodes = torch.arange(n, dtype=torch.int64, device=random_walk_sampler.graph.device)

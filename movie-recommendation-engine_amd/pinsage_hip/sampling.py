@@ -173,6 +173,65 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
     return NeighborBatch(ids, counts, nvalid)
 
 
+def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None,
+                       stream_nodes=None):
+    """`layers` consecutive batch_sample_neighbors calls over the same start nodes (PinSage.get_embeddings,
+    model/pinsage.py:271-275) as ONE kernel launch (ps_walk_sample_layers) -> list of NeighborBatch.  Bit-identical
+    to `layers` walk_sample calls: Philox uses call, call + 1, ...; rng='numpy' draws all layers' uniforms from the
+    global stream in one go (layer 0's, then layer 1's, ... as the reference consumes them) and hands the state back
+    once.  `nodes` may be a python range (no host sync in the steady state)."""
+    dev = graph.device
+    as_range = nodes if isinstance(nodes, range) else None
+    if as_range is not None:
+        if as_range.step != 1 or as_range.start < 0 or as_range.stop > graph.V:
+            raise IndexError("list index out of range")
+        starts = torch.arange(as_range.start, as_range.stop, dtype=torch.int64, device=dev)
+    else:
+        starts = _nodes_tensor(nodes, dev, graph.V)
+    B = int(starts.numel())
+    ids = torch.empty((layers, B, T), dtype=torch.int32, device=dev)
+    counts = torch.empty((layers, B, T), dtype=torch.int32, device=dev)
+    nvalid = torch.empty((layers, B), dtype=torch.int32, device=dev)
+    stride = 0
+    with torch.cuda.device(dev):
+        if rng == "numpy":
+            if graph.has_reachable_sink:
+                raise NotImplementedError("rng='numpy' needs a graph without reachable sinks; use rng='philox'")
+            # stream offsets: a property of (graph, start nodes, W * L), not of the RNG state.  For a python range of
+            # start nodes (what get_embeddings and item shards sample) they are computed once per graph and kept in
+            # HBM, like the CSR itself; anything else runs ps_uniform_offsets per call.
+            src = stream_nodes[0] if stream_nodes is not None else (as_range if as_range is not None else starts)
+            lo = stream_nodes[1] if stream_nodes is not None else 0
+            key = ("uoff", src.start, src.stop, W * L) if isinstance(src, range) and src.step == 1 else None
+            cache = graph.__dict__.setdefault("_stream_offsets", {})
+            if key is not None and key in cache:
+                uoff_all, stride = cache[key]
+            else:
+                all_t = (torch.arange(src.start, src.stop, dtype=torch.int64, device=dev)
+                         if isinstance(src, range) else _nodes_tensor(src, dev, graph.V))
+                total = torch.empty(1, dtype=torch.int64, device=dev)
+                uoff_all = torch.empty(all_t.numel(), dtype=torch.int64, device=dev)
+                nv.call("ps_uniform_offsets", nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(all_t),
+                        nv.i64(all_t.numel()), nv.i32(W), nv.i32(L), nv.ptr(uoff_all), nv.ptr(total), nv.stream())
+                stride = int(total.item())
+                if key is not None:
+                    cache[key] = (uoff_all, stride)
+            uoff = uoff_all if stream_nodes is None else uoff_all[lo:lo + B].contiguous()
+            if uniforms is None:
+                uniforms = draw_numpy_uniforms(layers * stride, dev)
+            mode = nv.PS_RNG_STREAM
+        elif rng == "philox":
+            uoff, uniforms, mode = None, None, nv.PS_RNG_PHILOX
+        else:
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        nv.call("ps_walk_sample_layers", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
+                nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T), nv.i32(mode), nv.ptr(uniforms), nv.ptr(uoff),
+                nv.i64(stride), nv.u64(seed & (2 ** 64 - 1)), nv.u32(call), nv.ptr(graph.nodeinfo), nv.ptr(graph.guide),
+                nv.ptr(graph.packed), nv.ptr(getattr(graph, "buckets", None)), nv.i32(layers), nv.ptr(ids), nv.ptr(counts),
+                nv.ptr(nvalid), nv.stream())
+    return [NeighborBatch(ids[r], counts[r], nvalid[r]) for r in range(layers)]
+
+
 def walk_paths(graph, starts, L, rng="numpy", seed=0, call=0, walk_mod=0):
     """One walk per start node: int32[B,L] visited nodes (-1 after a sink)."""
     dev = graph.device

@@ -96,6 +96,13 @@ class HipOps:
             return sampler.sample_batch(nodes, T, stream_nodes=(all_nodes, lo))
         return sampler.sample_batch(nodes, T)
 
+    def sample_layers(self, sampler, lo, hi, T, layers, shard=None):
+        """all layers' samples of the item range [lo, hi) in one launch (ps_walk_sample_layers)"""
+        stream = None
+        if shard is not None and getattr(sampler, "rng", None) == "numpy":
+            stream = (range(shard[0]), shard[1])
+        return sampler.sample_batches(range(lo, hi), T, layers, stream_nodes=stream)
+
     def pool(self, h_full, batch, max_idx):
         return sampling.importance_pool(h_full, batch, max_idx=max_idx)
 
@@ -172,7 +179,10 @@ class ShardedPinSage:
         # order) while the main stream runs the projections; each pooling waits for its own batch only.
         side = self._side_stream(dev) if (self.overlap_sampling and x_local.is_cuda) else None
         batches, ready = [], []
-        if side is not None:
+        fused = side is None and hasattr(ops, "sample_layers") and hasattr(self.sampler, "sample_batches")
+        if fused:
+            batches = list(ops.sample_layers(self.sampler, self.lo, self.hi, T, self.num_layers, shard))
+        elif side is not None:
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -192,7 +202,7 @@ class ShardedPinSage:
             h = ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
             pending = all_gather_rows_async(h, self.chunk, self.group)
         for i in range(self.num_layers):
-            if side is None and i + 1 < self.num_layers:
+            if side is None and not fused and i + 1 < self.num_layers:
                 batches.append(self._sample(nodes, T, shard))       # enqueued while layer i's rows are gathered
             H = h.size(1)
             Wu = P[f"convs.{i}.lin_update.weight"]

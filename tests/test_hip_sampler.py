@@ -334,3 +334,43 @@ def test_integration_md_ctypes_stub_reproduces_the_golden(golden):
         k = int(nvl[i])
         assert ids[i, :k].tolist() == g[pre + "ids"][i, :k].tolist()
         assert (cnt[i, :k] / cnt[i, :k].sum()).tolist() == g[pre + "weights"][i, :k].tolist()
+
+
+@pytest.mark.parametrize("W,L,T,layers", [(100, 2, 10, 2), (100, 2, 50, 3), (10, 3, 5, 2), (130, 1, 7, 4)])
+def test_fused_layer_sampling_equals_separate_calls(W, L, T, layers):
+    """ps_walk_sample_layers (all GCN layers' samples of a node in one wave; model/pinsage.py:271-275 draws them as
+    consecutive batch_sample_neighbors calls) vs `layers` separate launches, in both RNG modes: ids, counts, nvalid
+    bit-identical, and in numpy mode the same final np.random state.  Isolated start nodes included."""
+    from pinsage_hip.shard import HipOps
+    from utils.random_walk import RandomWalkSampler
+    ei, ew = bipartite_graph(2500, 1800, 120000, 5, "half")
+    keep = ~np.isin(ei[1][: ei.shape[1] // 2], [0, 77, 2499])
+    keep2 = np.concatenate([keep, keep])
+    ei, ew = ei[:, keep2], ew[keep2]
+    M = 2500
+    for rng in ("philox", "numpy"):
+        a = RandomWalkSampler(torch.from_numpy(ei), torch.from_numpy(ew), walk_length=L, num_walks=W, rng=rng, seed=9)
+        b = RandomWalkSampler.from_graph(a.graph, walk_length=L, num_walks=W, rng=rng, seed=9)
+        np.random.seed(123)
+        sep = [a.sample_batch(torch.arange(M, device=a.graph.device), T) for _ in range(layers)]
+        tail = np.random.random_sample()
+        for trial in range(2):                                   # the second pass answers the stream total from the cache
+            c = RandomWalkSampler.from_graph(a.graph, walk_length=L, num_walks=W, rng=rng, seed=9)
+            np.random.seed(123)
+            fused = c.sample_batches(range(M), T, layers)
+            assert np.random.random_sample() == tail
+            assert len(fused) == layers and c._calls == layers
+            for f, s in zip(fused, sep):
+                assert torch.equal(f.ids, s.ids) and torch.equal(f.counts, s.counts) and torch.equal(f.nvalid, s.nvalid)
+            assert int((fused[0].nvalid == 0).sum()) == 3
+        # tensor start nodes (not a range) and an item shard of the catalogue
+        np.random.seed(123)
+        fused = b.sample_batches(torch.arange(M), T, layers)
+        assert all(torch.equal(f.ids, s.ids) for f, s in zip(fused, sep))
+        lo, hi = 700, 1900
+        np.random.seed(123)
+        d = RandomWalkSampler.from_graph(a.graph, walk_length=L, num_walks=W, rng=rng, seed=9)   # Philox call counter at 0
+        part = HipOps().sample_layers(d, lo, hi, T, layers, shard=(M, lo))
+        assert np.random.random_sample() == tail or rng == "philox"
+        for f, s in zip(part, sep):
+            assert torch.equal(f.ids, s.ids[lo:hi]) and torch.equal(f.counts, s.counts[lo:hi])

@@ -42,20 +42,20 @@ def test_raw_sequence_is_numpys_stream():
 
 
 def test_radix_polynomials_agree_with_the_binary_table():
-    """entry (i, j-1) = t^(j * 2^(c + 4i)): the multipliers 1, 2, 4, 8 of a level are rows of the binary table, and
+    """entry (i, j-1) = t^(j * 2^(c + 5i)): the multipliers 1, 2, 4, 8, 16 of a level are rows of the binary table, and
     every other entry is a product of two smaller ones (checked through the recurrence on one window)."""
     from pinsage_hip import mtjump
     c = 17
     R, B = mtjump.radix_polynomials(c), mtjump.jump_polynomials()
-    assert R.shape == (mtjump.RADIX_LEVELS, 15, 624) and R.dtype == np.uint32
+    assert R.shape == (mtjump.RADIX_LEVELS, 31, 624) and R.dtype == np.uint32
     for i in range(mtjump.RADIX_LEVELS):
-        for b, j in enumerate((1, 2, 4, 8)):
-            if c + 4 * i + b < mtjump.JUMP_LEVELS:
-                assert np.array_equal(R[i, j - 1], B[c + 4 * i + b])
+        for b, j in enumerate((1, 2, 4, 8, 16)):
+            if c + 5 * i + b < mtjump.JUMP_LEVELS:
+                assert np.array_equal(R[i, j - 1], B[c + 5 * i + b])
     # t^(3u) = t^(u) * t^(2u): applying the jumps u then 2u to a window equals the single jump 3u
     phi = mtjump.characteristic_polynomial()
     as_int = lambda row: int.from_bytes(row.astype("<u4").tobytes(), "little")
-    for i, j in ((0, 3), (0, 7), (1, 5), (2, 15)):
+    for i, j in ((0, 3), (0, 7), (1, 5), (2, 15), (0, 31), (1, 22)):
         a, b = (j & -j), j - (j & -j)                              # split j into two smaller multipliers
         prod = mtjump._reduce(mtjump._mul(as_int(R[i, a - 1]), as_int(R[i, b - 1])), phi)
         assert prod == as_int(R[i, j - 1])
