@@ -20,6 +20,19 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "reference_golden.npz"))
 
 
+@pytest.fixture(scope="session")
+def golden2():
+    """round-2 fixtures generated from the reference by tests/golden/make_golden_r2.py (G7, G8, G10, G11)"""
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_golden_r2.npz"))
+
+
+@pytest.fixture(scope="session")
+def surface():
+    """G9: ast-derived signatures of the reference's four hot-path modules (tests/golden/surface.json)"""
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "surface.json")))
+
+
 def bipartite_graph(M, U, R, seed, weights="half"):
     """Synthetic user-item graph in the reference's layout (data/dataset.py:101-116)."""
     rs = np.random.RandomState(seed)

@@ -149,7 +149,10 @@ def test_aggregators_golden(golden):
     with torch.no_grad():
         np.testing.assert_allclose(A.MeanAggregator()(f, nbrs).cpu().numpy(), g["g4_mean"], rtol=RTOL, atol=ATOL)
         np.testing.assert_allclose(A.WeightedAggregator()(f, nbrs, wts).cpu().numpy(), g["g4_weighted"], rtol=RTOL, atol=ATOL)
-        np.testing.assert_allclose(ia(f, nbrs, wts).cpu().numpy(), g["g4_importance"], rtol=1e-4, atol=1e-5)
+        got = ia(f, nbrs, wts).cpu().numpy()
+        err = np.abs(got - g["g4_importance"]) / (np.abs(g["g4_importance"]) + 1e-6)
+        print("ImportanceAggregator max rel err", float(err.max()))
+        np.testing.assert_allclose(got, g["g4_importance"], rtol=RTOL, atol=ATOL)             # north_star: 1e-5 rel
         np.testing.assert_allclose(at(f, nbrs).cpu().numpy(), g["g4_attention"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(mp(f, nbrs).cpu().numpy(), g["g4_maxpool"], rtol=1e-5, atol=1e-6)
     with pytest.raises(IndexError):
@@ -396,7 +399,7 @@ def test_graphconv_edge_branch_hip_vs_torch():
     with torch.no_grad():
         ref = m(x, edge_index=ei)                              # CPU: torch index_add_ path
         out = m.cuda()(x.cuda(), edge_index=ei.cuda()).cpu()    # GPU, no grad: ps_spmm_csr
-    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
     # with autograd the differentiable path runs and gradients reach the parameters
     m.train()
     e = m(x.cuda(), edge_index=ei.cuda())

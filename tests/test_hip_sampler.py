@@ -374,3 +374,39 @@ def test_fused_layer_sampling_equals_separate_calls(W, L, T, layers):
         assert np.random.random_sample() == tail or rng == "philox"
         for f, s in zip(part, sep):
             assert torch.equal(f.ids, s.ids[lo:hi]) and torch.equal(f.counts, s.counts[lo:hi])
+
+
+def test_hard_negatives_match_the_reference(golden2):
+    """G7: NegativeSampler.sample_hard_negatives of the reference (data/negative_sampler.py:44-99) on the reference's
+    sampler vs pinsage_hip.negatives on the HIP sampler, rng='numpy': the candidate branch (narrow rank window), the
+    fill-up branch (fewer candidates than requested) and the fallback branch (default window) -- same indices, same
+    np.random position afterwards."""
+    from pinsage_hip.negatives import sample_hard_negatives
+    from utils.random_walk import RandomWalkSampler
+    g = golden2
+    s = RandomWalkSampler(torch.from_numpy(g["g7_edge_index"]), torch.from_numpy(g["g7_edge_weights"]),
+                          walk_length=2, num_walks=100)
+    q = torch.from_numpy(g["g7_queries"])
+    for tag in ("window", "short", "default"):
+        nh, mx, mn = [int(v) for v in g[f"g7_{tag}_args"]]
+        np.random.seed(31)
+        out = sample_hard_negatives(s, int(g["g7_num_movies"]), q, num_hard_samples=nh, max_rank=mx, min_rank=mn)
+        assert out.dtype == torch.int64 and np.array_equal(out.numpy(), g[f"g7_{tag}_out"]), tag
+        assert np.random.random_sample() == float(g[f"g7_{tag}_tail"]), tag
+
+
+def test_ppr_helpers_match_the_reference(golden2):
+    """G11: compute_ppr_matrix / precompute_top_neighbors (utils/random_walk.py:144-229; dead code upstream but on the
+    class surface): same (source, target) keys, scores to 1e-12, same top-neighbour ids and normalised weights."""
+    from utils.random_walk import RandomWalkSampler
+    g = golden2
+    s = RandomWalkSampler(torch.from_numpy(g["g11_edge_index"]), torch.from_numpy(g["g11_edge_weights"]),
+                          walk_length=2, num_walks=10)
+    nodes = [int(v) for v in g["g11_nodes"]]
+    ppr = s.compute_ppr_matrix(nodes, alpha=0.15, num_iterations=4)
+    keys = sorted(ppr)
+    assert np.array_equal(np.array(keys, dtype=np.int64), g["g11_ppr_keys"])
+    np.testing.assert_allclose([ppr[k] for k in keys], g["g11_ppr_vals"], rtol=1e-12, atol=0)
+    top = s.precompute_top_neighbors(nodes, num_neighbors=4)
+    assert np.array_equal(np.array([top[n][0] for n in nodes]), g["g11_top_ids"])
+    np.testing.assert_allclose(np.array([top[n][1] for n in nodes]), g["g11_top_w"], rtol=1e-12, atol=0)
