@@ -211,3 +211,50 @@ def test_config5_shaped_graph_without_bucket_records():
     # items of this graph may be unrated (isolated): they return the empty result on both paths
     iso = (gb.rowptr[nodes + 1] - gb.rowptr[nodes]) == 0
     assert bool((a.nvalid[iso] == 0).all()) and bool((a.nvalid[~iso] > 0).all())
+
+
+def test_whole_step_is_hipgraph_capturable(big):
+    """include/pinsage_hip.h promises that every call only enqueues work on the given stream (no allocation, no
+    synchronisation, no global state): one whole step -- two-layer sampling, pooling, the four GEMMs, LSH encode + sign
+    planes, the three Hamming passes and the merge -- is captured into ONE hipGraph and replayed; every replay must
+    return exactly what the eager launches return (Philox mode: the numpy-stream mode hands the RNG state back to the
+    host, which is a synchronisation by definition)."""
+    from pinsage_hip.shard import ShardedPinSage
+    from utils.nearest_neighbors import lsh_rotation_matrix
+    from utils.random_walk import RandomWalkSampler
+    from model.pinsage import PinSage
+    g, ei, ew = big
+    M, T, D, nbits, k, nq = 59047, 10, 256, 512, 11, 10000
+    dev = g.device
+    torch.manual_seed(2)
+    model = PinSage(128, 256, D, 2).to(dev).eval()
+    params = {n: v.detach().float().contiguous() for n, v in model.state_dict().items()}
+    x = torch.randn(M, 128, device=dev)
+    A = torch.from_numpy(lsh_rotation_matrix(D, nbits)).to(dev)
+    smp = RandomWalkSampler.from_graph(g, 2, 100, rng="philox", seed=42)
+    pipe = ShardedPinSage(params, 2, smp, M)
+
+    def step():
+        smp._calls = 0                                   # the Philox call index is a launch argument: baked into the graph
+        emb = pipe.embed(x, T)
+        pipe.build_index(emb, A)
+        d, i = pipe.search(emb[:nq], k)
+        return emb, d, i
+
+    with torch.no_grad():
+        e0, d0, i0 = step()                              # eager (also warms allocator pools and one-time attributes)
+        step()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            step()                                       # warm-up on the capture stream
+            with torch.cuda.graph(graph, stream=side):
+                e1, d1, i1 = step()
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(3):
+            e1.zero_(); d1.zero_(); i1.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(e1, e0) and torch.equal(d1, d0) and torch.equal(i1, i0)

@@ -11,7 +11,9 @@ from utils.random_walk import RandomWalkSampler
 from utils.nearest_neighbors import lsh_rotation_matrix
 from model.pinsage import PinSage
 
-ap = argparse.ArgumentParser(); ap.add_argument("--worlds", default="1,2,4,8"); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--worlds", default="1,2,4,8")
+ap.add_argument("--graph", action="store_true", help="also time the step replayed from ONE captured hipGraph")
+a = ap.parse_args()
 dev = torch.device("cuda")
 U, M, R = synth.ML25M["num_users"], synth.ML25M["num_items"], synth.ML25M["num_ratings"]
 ei, ew = synth.bipartite_ratings(U, M, R, device=dev)
@@ -55,5 +57,22 @@ for world in [int(w) for w in a.worlds.split(",")]:
     for _ in range(10):
         step()
     ks = tm.summary(); nv.set_timer(None)
-    print(f"world {world}: {ms:.3f} ms per step (compute only, rank 0 of {world}; host enqueue {host_ms:.3f} ms); "
+    gms = None
+    if a.graph:
+        with torch.no_grad():
+            side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                smp._calls = 0; step()
+                with torch.cuda.graph(gr, stream=side):
+                    smp._calls = 0; step()
+            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(20):
+                gr.replay()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(50):
+                gr.replay()
+            torch.cuda.synchronize(); gms = (time.perf_counter() - t0) / 50 * 1e3
+    print(f"world {world}: {ms:.3f} ms per step (compute only, rank 0 of {world}; host enqueue {host_ms:.3f} ms"
+          + (f"; replayed from one hipGraph {gms:.3f} ms" if gms is not None else "") + "); "
           + ", ".join(f"{k[3:]} {v['ms'] / 10:.3f}" for k, v in ks.items()), flush=True)
