@@ -232,6 +232,19 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
     };
 
     // ---- sweep: ring of NBUF item tiles, one barrier per tile ----
+    // Measured alternatives that were NOT faster on MI355X (10 000 x 59 047 x 512 bit; collect pass 338 us + bound pass
+    // 58 us as written):
+    //  * 2 query tiles per wave (each LDS fragment feeds two MFMAs; 250 VGPRs, candidate columns in global memory): 561 us
+    //    -- with the sweep's matrix work alone (no epilogue) 222 us vs 233 us: the LDS reads were never the limit;
+    //  * the two waves of a SIMD half a tile apart (one multiplies while the other reads fragments), with one and with
+    //    two accumulation chains per wave: 381 / 399 us -- the matrix loop alone 253 / 227 us;
+    //  * a shared per-query histogram of admitted candidates (atomics + L1-bypassing re-reads every 8 tiles) that lets
+    //    every lane tighten its threshold during the sweep: the candidates per query drop 3x and the bound pass can
+    //    shrink to 2.5 % of the table, but the histogram's own memory operations sit in the ring's counted vmcnt
+    //    waits: 383 - 399 us + 34 us, the same total;
+    //  * the matrix loop alone on constant codes: 174 us vs 204 us on random codes on the same box (and 204 - 233 us
+    //    between boxes): the loop runs at the clock the chip holds under int8 MFMA load (SQ_VALU_MFMA_BUSY_CYCLES =
+    //    32 cycles x the 9.45 M MFMAs of a sweep = 295 K cycles per SIMD, i.e. 123 us at the 2.4 GHz the peak is quoted at).
     // query fragments / bounds are in: nothing of the compiler's is in flight from here on.  The builtin form, so that
     // hipcc's own wait-count pass knows it (an asm wait is invisible to it and it would wait vmcnt(0) again at the
     // first use of a query fragment INSIDE the loop, i.e. drain the ring on every tile)

@@ -17,6 +17,8 @@ k = int(sys.argv[4]) if len(sys.argv) > 4 else 11
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
 g = torch.Generator().manual_seed(0)
 codes = torch.randint(0, 256, (N, nbits // 8), generator=g, dtype=torch.uint8).cuda()
+if os.environ.get("PS_BENCH_CODES") == "zeros":            # data-dependent power / clock probe (probe libraries only)
+    codes.zero_()
 q = codes[torch.randperm(N, generator=g)[:nq].cuda()].contiguous()
 planes = dense.lsh_expand(codes)
 

@@ -25,7 +25,7 @@ names = sorted(set(F) | set(Wr), key=lambda k: -(F[k][0] + Wr[k][0]))
 lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `bench.py --steps %d --warmup 1 --no-cpu-baseline`" % steps,
          "values: KB per launch (mean over launches), as reported (FETCH_SIZE = TCC_EA0_RDREQ x 64 B; no wide-stream correction applied)", ""]
 for k in names:
-    own = any(t in k for t in ("walk_", "gemm_f32", "hamming", "importance_pool", "topk_merge", "cdf_", "guide_", "pack_", "bucket_", "gather_kernel", "mt_", "spmm"))
+    own = any(t in k for t in ("walk_", "gemm_f32", "hamming", "importance_pool", "topk_merge", "slice_merge", "bound_select", "lsh_expand", "cdf_", "guide_", "pack_", "bucket_", "gather_kernel", "mt_", "spmm"))
     if not own:
         continue
     nf, nw = F[k][1] or 1, Wr[k][1] or 1
@@ -52,6 +52,12 @@ def per_call(pred):
 out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps {steps} --warmup 1 --no-cpu-baseline ({label})",
        "units": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB * 1024, as reported (no gfx950 wide-stream correction applied: narrow gathers are uncalibrated)",
        "ps_walk_sample": per_launch(lambda k: k.startswith("walk_sample_kernel")),
+       "ps_walk_sample_layers": per_launch(lambda k: k.startswith("walk_sample_kernel")),
+       "ps_hamming_topk_mfma": per_launch(lambda k: k.startswith("hamming_mfma_kernel") or k.startswith("bound_select_kernel")
+                                          or k.startswith("slice_merge_kernel")),
+       "ps_mt19937_random_sample": per_launch(lambda k: k.startswith("mt_chunk_kernel") or k.startswith("mt_raw_to_double")
+                                              or k.startswith("mt_final_state") or k.startswith("mt_prepare")) +
+                                   3 * per_launch(lambda k: k.startswith("mt_combine_radix") or k.startswith("mt_expand")),
        "ps_importance_pool": per_launch(lambda k: k.startswith("importance_pool_kernel")),
        "ps_linear": per_call(lambda k: k.startswith("gemm_f32_kernel") and ", 0, " in k),
        "ps_lsh_encode": per_call(lambda k: k.startswith("gemm_f32_kernel") and ", 1, " in k),
