@@ -35,14 +35,20 @@ __device__ __forceinline__ uint32_t temper(uint32_t y) {
     return y;
 }
 
-// next 624 words from the previous 624 (o -> n), all threads of the block; 3 dependency phases
+// next 624 words from the previous 624 (o -> n), all threads of the block, ONE barrier: thread t produces n[t],
+// n[t + 227] and n[t + 454] in turn -- n[i] = n[i - 227] ^ twist(o[i], o[i + 1]) for i >= 227 needs only the thread's
+// own previous result and words of the OLD block; the single exception n[623] = n[396] ^ twist(o[623], n[0]) takes n[0]
+// from old words too (thread 169 recomputes it).  The first version synchronised after each of the three phases:
+// 161 us per 2^17-word chunk instead of ~70.
 __device__ __forceinline__ void next_block(const uint32_t *o, uint32_t *n, int t) {
-    if (t < 227) n[t] = o[t + MT_M] ^ twist(o[t], o[t + 1]);
-    __syncthreads();
-    if (t < 227) { const int i = 227 + t; n[i] = n[i - 227] ^ twist(o[i], o[i + 1]); }
-    __syncthreads();
-    if (t < 169) { const int i = 454 + t; n[i] = n[i - 227] ^ twist(o[i], o[i + 1]); }
-    else if (t == 169) n[623] = n[396] ^ twist(o[623], n[0]);      // its inputs are phase-1 / phase-2 words
+    if (t < 227) {
+        const uint32_t a = o[t + MT_M] ^ twist(o[t], o[t + 1]);
+        const uint32_t b = a ^ twist(o[227 + t], o[228 + t]);
+        n[t] = a;
+        n[227 + t] = b;
+        if (t < 169) n[454 + t] = b ^ twist(o[454 + t], o[455 + t]);
+        else if (t == 169) n[623] = b ^ twist(o[623], o[MT_M] ^ twist(o[0], o[1]));
+    }
     __syncthreads();
 }
 
