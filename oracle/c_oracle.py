@@ -10,6 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liboracle.so")
+_SO_OVERRIDE = os.environ.get("PS_ORACLE_SO")          # `make -C oracle asan-test`: the sanitizer build of the same source
 _lib = None
 
 
@@ -23,8 +24,11 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        if _SO_OVERRIDE:
+            _lib = C.CDLL(os.path.abspath(_SO_OVERRIDE))
+        else:
+            build()
+            _lib = C.CDLL(_SO)
         _lib.orc_np_sum.restype = C.c_double
     return _lib
 
