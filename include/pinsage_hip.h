@@ -178,16 +178,17 @@ int ps_hamming_topk(const uint8_t *qcodes, int64_t nq, const uint8_t *codes, int
                     int64_t id_offset, int32_t *dist, int64_t *ids,
                     void *workspace, size_t workspace_bytes, ps_stream_t stream);
 
-/* The same search as an exact int8 contraction on the matrix cores (csrc/hamming_mfma.hip): every code is expanded
- * ONCE into "sign planes" -- bit j of a code -> byte +1 / -1, laid out tile by tile (32 codes x 32 bits = 1 KiB) in
- * the order v_mfma_i32_32x32x32_i8 consumes them -- and dot(q, x) = nbits - 2 * hamming(q, x) exactly.
+/* The same search as an exact contraction on the matrix cores (csrc/hamming_mfma.hip): every code is expanded
+ * ONCE into "sign planes" -- bit j of a code -> an fp4 (e2m1) +1 / -1, laid out tile by tile (32 codes x 64 bits = 1 KiB)
+ * in the order v_mfma_scale_f32_32x32x64_f8f6f4 consumes them -- and dot(q, x) = nbits - 2 * hamming(q, x) exactly (the
+ * products are +-1, the partial sums integers far below 2^24).
  * Replaces the same reference lines as ps_hamming_topk (utils/nearest_neighbors.py:47-68 -> faiss hammings_knn_hc)
  * and returns bit-identical (dist, ids).
- *   ps_lsh_planes_bytes(n, cs)      : size of the plane table of n codes (0 if cs is not a multiple of 4)
+ *   ps_lsh_planes_bytes(n, cs)      : size of the plane table of n codes = 4 x the packed codes (0 if cs % 8 != 0)
  *   ps_lsh_expand(codes, n, cs, pl) : builds it (16-B aligned); done at LSHIndex.build time for the table, per call
  *                                     for the queries
- *   ps_hamming_topk_mfma_workspace_bytes : 0 when the shape is not served (k > 32, code size not 4..64 bytes in powers
- *                                     of two, fewer than 64 queries or 4096 items): callers use ps_hamming_topk then;
+ *   ps_hamming_topk_mfma_workspace_bytes : 0 when the shape is not served (k > 32, code size not 8 / 16 / 32 / 64 bytes,
+ *                                     fewer than 64 queries or 4096 items): callers use ps_hamming_topk then;
  *                                     ps_hamming_topk_mfma itself returns PS_EUNSUPPORTED for such shapes. */
 size_t ps_lsh_planes_bytes(int64_t n, int cs);
 int ps_lsh_expand(const uint8_t *codes, int64_t n, int cs, void *planes, ps_stream_t stream);

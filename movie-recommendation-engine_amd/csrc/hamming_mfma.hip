@@ -1,14 +1,19 @@
 // hamming_mfma.hip -- the Hamming k-NN scan of faiss.IndexLSH.search (reference utils/nearest_neighbors.py:47-68)
 // as an EXACT integer contraction on the gfx950 matrix cores.
 //
-// A code of nbits bits is expanded once into nbits int8 values s_j = +1 (bit set) / -1 (bit clear).  Then
-//     dot(q, x) = sum_j s_j(q) s_j(x) = nbits - 2 * hamming(q, x)        (an integer, exact in i32)
-// so the all-pairs distance table is a GEMM, evaluated with v_mfma_i32_32x32x32_i8; zero bytes (padding rows)
-// contribute nothing.  Results are bit-identical to the popcount scan (csrc/hamming_topk.hip): the k smallest by
+// A code of nbits bits is expanded once into nbits values s_j = +1 (bit set) / -1 (bit clear).  Then
+//     dot(q, x) = sum_j s_j(q) s_j(x) = nbits - 2 * hamming(q, x)        (an integer)
+// so the all-pairs distance table is a GEMM.  The signs are stored as fp4 (e2m1: +1 = 0x2, -1 = 0xA, padding 0x0) and
+// contracted with the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (both block scales 2^0): every product is +-1 or 0
+// and every partial sum an integer below 2^24, so the f32 accumulator is exact (tools/ubench/mfma_fp4_probe.hip checks
+// the instruction against an integer dot product and times it: 16.0 ns per 32x32x64 MFMA per SIMD = 8.4 POP/s of sign
+// products on random data, 2.2 x the int8 form v_mfma_i32_32x32x32_i8 that the first version of this file used, at half
+// the operand bytes).  Results are bit-identical to the popcount scan (csrc/hamming_topk.hip): the k smallest by
 // (distance, id), ascending.
 //
-// Sign planes ("fragment order"): for a tile of 32 codes and a 32-bit K step s, one 1 KiB block
-//     planes[(tile * KS + s) * 1024 + lane * 16 + j] = s_{32 s + 16 (lane >> 5) + j}(code 32 tile + (lane & 31))
+// Sign planes ("fragment order"): for a tile of 32 codes and a 64-bit K step s, one 1 KiB block; lane `lane`'s 16 bytes
+//     planes[(tile * KS + s) * 1024 + lane * 16 ..] = the 32 nibbles s_{64 s + 32 (lane >> 5) + j}(code 32 tile + (lane & 31)),
+//     j = 0..31, low nibble first
 // i.e. exactly the 16 bytes lane `lane` feeds to the MFMA as its A (items) or B (queries) operand, so a tile is
 // brought into LDS by global_load_lds_dwordx4 (no registers, lane-linear image, conflict-free ds_read_b128) and a
 // query tile is 16 coalesced dwordx4 loads into registers.  A and B use the same (lane half, byte) -> k map, so the
@@ -32,7 +37,8 @@
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 // experiments only (tools/hm_probe.sh builds variants with -DPS_HM_DEBUG=bits; results are WRONG with any bit set):
 // 1 no tile epilogue, 2 no LDS-DMA, 4 no barrier, 8 no MFMA, 16 no fragment reads
@@ -43,10 +49,11 @@ constexpr uint32_t EMPTY_KEY = 0xffffffffu;
 constexpr int NBUF = 3;
 constexpr int CAP = 48;                    // slots of a lane's candidate column (LDS); compacted beyond 32
 constexpr int WAVES = 8;
-constexpr int NO_DOT = -(1 << 20);          // "no item": below every real dot (|dot| <= 1024)
+constexpr int IT = 2;                       // item tiles (32 codes each) per ring entry = per barrier; planes are padded to whole entries
+constexpr float NO_DOT = -1048576.0f;       // "no item": below every real dot (|dot| <= 1024)
 
 // ---- sign planes ------------------------------------------------------------------------------------------------
-// one thread = one 16-byte piece (tile, step, lane)
+// one thread = one 16-byte piece (tile, step, lane): the 32 code bits of word 2 s + (lane >> 5) as 32 fp4 nibbles
 __global__ __launch_bounds__(256) void lsh_expand_kernel(const uint32_t *__restrict__ codes, int64_t n, int KS,
                                                          int64_t pieces, uint4 *__restrict__ planes) {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pieces; p += (int64_t)gridDim.x * blockDim.x) {
@@ -57,13 +64,12 @@ __global__ __launch_bounds__(256) void lsh_expand_kernel(const uint32_t *__restr
         const int64_t row = tile * 32 + (lane & 31);
         uint4 o = make_uint4(0u, 0u, 0u, 0u);
         if (row < n) {
-            const uint32_t bits = (codes[row * KS + s] >> (16 * (lane >> 5))) & 0xffffu;
-            // 4 bits -> 4 bytes of +1 (0x01) / -1 (0xff): spread with a 24-bit multiply, then 0xff ^ (b * 0xfe)
-            auto four = [](uint32_t nib) {
-                const uint32_t b = (nib * 0x00204081u) & 0x01010101u;
-                return 0xffffffffu ^ (b * 0xfeu);
-            };
-            o.x = four(bits & 15u); o.y = four((bits >> 4) & 15u); o.z = four((bits >> 8) & 15u); o.w = four(bits >> 12);
+            const uint32_t bits = codes[row * (2 * KS) + 2 * s + (lane >> 5)];
+            // 8 bits -> 8 nibbles: bit b -> +1 (0x2) / -1 (0xA) = 0xA ^ (b << 3); four bits are spread to the nibble
+            // positions 0, 4, 8, 12 by OR-ing shifted copies (a multiply would carry between the overlapping copies)
+            auto four = [](uint32_t n) { return (n | (n << 3) | (n << 6) | (n << 9)) & 0x1111u; };
+            auto eight = [&](uint32_t byte) { return 0xaaaaaaaau ^ ((four(byte & 15u) | (four(byte >> 4) << 16)) << 3); };
+            o.x = eight(bits & 255u); o.y = eight((bits >> 8) & 255u); o.z = eight((bits >> 16) & 255u); o.w = eight(bits >> 24);
         }
         planes[p] = o;
     }
@@ -97,11 +103,18 @@ __device__ __forceinline__ void lds_dma16(const void *gptr, uint32_t lds_byte_of
 }
 #pragma clang diagnostic pop
 
-__device__ __forceinline__ int max16(const v16i &a) {
-    int m = max(max(a[0], a[1]), a[2]);
-    m = max(max(m, a[3]), a[4]);  m = max(max(m, a[5]), a[6]);   m = max(max(m, a[7]), a[8]);
-    m = max(max(m, a[9]), a[10]); m = max(max(m, a[11]), a[12]); m = max(max(m, a[13]), a[14]);
-    return max(m, a[15]);
+__device__ __forceinline__ float max16(const v16f &a) {
+    float m = fmaxf(fmaxf(a[0], a[1]), a[2]);
+    m = fmaxf(fmaxf(m, a[3]), a[4]);  m = fmaxf(fmaxf(m, a[5]), a[6]);   m = fmaxf(fmaxf(m, a[7]), a[8]);
+    m = fmaxf(fmaxf(m, a[9]), a[10]); m = fmaxf(fmaxf(m, a[11]), a[12]); m = fmaxf(fmaxf(m, a[13]), a[14]);
+    return fmaxf(m, a[15]);
+}
+
+// one K step: 32 x 32 x 64 signs; only the first four registers of the 8-register operands are read for fp4
+__device__ __forceinline__ v16f sign_mfma(const v4i &a, const v4i &b, const v16f &c) {
+    const v8i A = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+    const v8i B = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
 // MODE 0 = bound pass, 1 = collect pass.  One wave = one tile of 32 queries (16 query-fragment registers per 32 bits
@@ -110,7 +123,9 @@ template <int KS, int MODE, int KM>
 __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     constexpr int TILE_BYTES = KS * 1024;
-    constexpr int PPW = (KS + WAVES - 1) / WAVES;          // LDS-DMA pieces per wave and tile
+    constexpr int ENTRY_BYTES = IT * TILE_BYTES;           // one ring entry = IT consecutive item tiles
+    constexpr int PIECES = IT * KS;                        // 1 KiB LDS-DMA pieces per entry
+    constexpr int PPW = (PIECES + WAVES - 1) / WAVES;      // pieces per wave and entry
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -130,9 +145,8 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
     int64_t t0 = a.tile_begin + (int64_t)slice * a.tiles_per_slice;
     int64_t t1 = t0 + a.tiles_per_slice;
     if (t1 > a.tile_end) t1 = a.tile_end;
-    const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
-    const int64_t last_tile = (a.N - 1) >> 5;               // the only tile that can hold padding rows
-    const int last_rows = (int)(a.N - last_tile * 32);
+    const int nt = t1 > t0 ? (int)((t1 - t0 + IT - 1) / IT) : 0;     // ring entries; t0 and tiles_per_slice are multiples of IT
+    const int64_t last_tile = (a.N - 1) >> 5;               // tiles from here on hold padding rows (zero nibbles)
 
     // query fragments (B operand): 16 bytes per K step, resident for the whole sweep
     v4i bq[KS];
@@ -144,21 +158,23 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
     }
 
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);       // low half of the flat address = LDS offset
-    auto prefetch = [&](int64_t t, int buf) {
+    // entry e of this slice = tiles t0 + IT e .. + IT - 1 = PIECES consecutive 1 KiB pieces of the plane table
+    auto prefetch = [&](int e, int buf) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int p = wv + WAVES * i;
-            if (p < KS && !(PS_HM_DEBUG & 2)) lds_dma16(a.dbplanes + ((t * KS + p) * 64 + lane) * 16, lds_base + (uint32_t)(buf * KS + p) * 1024u);
+            if (p < PIECES && !(PS_HM_DEBUG & 2))
+                lds_dma16(a.dbplanes + (((t0 + (int64_t)e * IT) * KS + p) * 64 + lane) * 16, lds_base + (uint32_t)(buf * PIECES + p) * 1024u);
         }
     };
 
     // ---- per-lane state ----
-    uint32_t *cand = reinterpret_cast<uint32_t *>(smem + NBUF * TILE_BYTES) + wv * (CAP * 64);   // [slot][lane]
+    uint32_t *cand = reinterpret_cast<uint32_t *>(smem + NBUF * ENTRY_BYTES) + wv * (CAP * 64);  // [slot][lane]
     int cnt = 0;
-    int thr = 0x7fffffff;                                   // admit iff dot >= thr
-    int best[KM];                                           // bound pass: KM largest group maxima of the dot, descending
+    float thr = 3.0e38f;                                    // admit iff dot >= thr (dots are integers held in f32)
+    float best[KM];                                         // bound pass: KM largest group maxima of the dot, descending
     if (MODE == 1) {
-        if (q_ok) thr = a.nbits - 2 * a.thr0[q];
+        if (q_ok) thr = (float)(a.nbits - 2 * a.thr0[q]);
     } else {
 #pragma unroll
         for (int j = 0; j < KM; ++j) best[j] = NO_DOT;
@@ -184,29 +200,30 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
         cnt = cnt < k ? cnt : k;
         if (cnt == k) {
             const int hk = (int)(cand[(k - 1) * 64 + lane] >> a.shift);
-            const int nthr = a.nbits - 2 * hk + 2;
+            const float nthr = (float)(a.nbits - 2 * hk + 2);
             thr = nthr > thr ? nthr : thr;
         }
     };
 
-    auto epilogue = [&](v16i acc, int i) {
+    auto epilogue = [&](v16f acc, int i) {
         const int64_t t = t0 + i;
-        if (t == last_tile && last_rows < 32) {             // wave-uniform: mask the padding rows of the table's end
+        if (t >= last_tile) {                               // wave-uniform: mask the padding rows of the table's end
+            const int64_t left = a.N - t * 32;              // valid rows of this tile (<= 0: a padding tile of the last entry)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if ((r & 3) + 8 * (r >> 2) + 4 * lh >= last_rows) acc[r] = NO_DOT;
+                if ((r & 3) + 8 * (r >> 2) + 4 * lh >= left) acc[r] = NO_DOT;
         }
         // maximum of the lane's 16 dots as a two-level tree: the four group maxima localise a hit
-        int g[4];
+        float g[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = max(max(max(acc[4 * j], acc[4 * j + 1]), acc[4 * j + 2]), acc[4 * j + 3]);
-        const int m = max(max(max(g[0], g[1]), g[2]), g[3]);
+        for (int j = 0; j < 4; ++j) g[j] = fmaxf(fmaxf(fmaxf(acc[4 * j], acc[4 * j + 1]), acc[4 * j + 2]), acc[4 * j + 3]);
+        const float m = fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), g[3]);
         if (MODE == 0) {
-            int x = m;
+            float x = m;
 #pragma unroll
             for (int j = 0; j < KM; ++j) {
-                const int hi = max(best[j], x);
-                x = min(best[j], x);
+                const float hi = fmaxf(best[j], x);
+                x = fminf(best[j], x);
                 best[j] = hi;
             }
             return;
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
                 const bool hit = acc[r] >= thr;
                 if (__ballot(hit) != 0ull) {
                     if (hit) {
-                        const uint32_t ham = (uint32_t)(a.nbits - acc[r]) >> 1;
+                        const uint32_t ham = (uint32_t)(a.nbits - (int)acc[r]) >> 1;
                         cand[cnt * 64 + lane] = (ham << a.shift) | (base + (r & 3) + 8 * (r >> 2));
                         ++cnt;
                     }
@@ -232,8 +249,10 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
     };
 
     // ---- sweep: ring of NBUF item tiles, one barrier per tile ----
-    // Measured alternatives that were NOT faster on MI355X (10 000 x 59 047 x 512 bit; collect pass 338 us + bound pass
-    // 58 us as written):
+    // History on MI355X (10 000 x 59 047 x 512 bit, k = 11): int8 signs (v_mfma_i32_32x32x32_i8), one tile per barrier:
+    // collect 338 us + bound 58 us; fp4 signs (half the MFMAs, half the bytes): 281 + 45; two tiles per barrier (two
+    // independent accumulation chains, half the barriers): 262 + 45 = 0.33 ms for the whole call, popcount kernel 0.71 ms.
+    // Measured alternatives that were NOT faster (int8 version, collect pass 338 us + bound pass 58 us):
     //  * 2 query tiles per wave (each LDS fragment feeds two MFMAs; 250 VGPRs, candidate columns in global memory): 561 us
     //    -- with the sweep's matrix work alone (no epilogue) 222 us vs 233 us: the LDS reads were never the limit;
     //  * the two waves of a SIMD half a tile apart (one multiplies while the other reads fragments), with one and with
@@ -251,53 +270,74 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
 #pragma unroll
     for (int j = 0; j < NBUF - 1; ++j)
-        if (j < nt) prefetch(t0 + j, j);
-    v16i acc_prev;
+        if (j < nt) prefetch(j, j);
+    v16f acc_prev[IT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc_prev[r] = NO_DOT;
+    for (int u = 0; u < IT; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_prev[u][r] = NO_DOT;
     int buf = 0;
     for (int i = 0; i < nt; ++i) {
-        // own pieces of tile i have landed (younger tiles' may be in flight); after the barrier everybody's have, and
-        // everybody has finished reading tile i-1, whose buffer the next LDS-DMA overwrites
+        // own pieces of entry i have landed (younger entries' may be in flight); after the barrier everybody's have, and
+        // everybody has finished reading entry i-1, whose buffer the next LDS-DMA overwrites
         const int younger = nt - 1 - i;
         if (younger >= NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NBUF - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(PS_HM_DEBUG & 4)) __builtin_amdgcn_s_barrier();
-        if (i + NBUF - 1 < nt) prefetch(t0 + i + NBUF - 1, buf >= 1 ? buf - 1 : NBUF - 1);
-        // all K steps' item fragments are requested at once (KS ds_read_b128 in flight; with the compiler's own 2-deep
-        // interleave the LDS round trip sat between every MFMA pair); a late wave's previous-tile epilogue runs under
-        // that latency
-        const unsigned char *tb = smem + buf * TILE_BYTES + lane * 16;
-        v4i av[KS];
+        if (i + NBUF - 1 < nt) prefetch(i + NBUF - 1, buf >= 1 ? buf - 1 : NBUF - 1);
+        // all item fragments of the entry are requested at once (IT * KS ds_read_b128 in flight; with the compiler's own
+        // 2-deep interleave the LDS round trip sat between every MFMA pair); a late wave's previous-entry epilogue runs
+        // under that latency.  The IT tiles are IT independent accumulation chains.
+        const unsigned char *tb = smem + buf * ENTRY_BYTES + lane * 16;
+        v4i av[IT][KS];
+#pragma unroll
+        for (int u = 0; u < IT; ++u)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                av[u][s] = (PS_HM_DEBUG & 16) ? v4i{i, s, lane, u} : *reinterpret_cast<const v4i *>(tb + (u * KS + s) * 1024);
+        __builtin_amdgcn_sched_group_barrier(0x100, IT * KS, 0);
+        if (late && i > 0 && !(PS_HM_DEBUG & 1)) {
+#pragma unroll
+            for (int u = 0; u < IT; ++u) epilogue(acc_prev[u], (i - 1) * IT + u);
+        }
+        v16f acc[IT];
+#pragma unroll
+        for (int u = 0; u < IT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-            av[s] = (PS_HM_DEBUG & 16) ? v4i{i, s, lane, 1} : *reinterpret_cast<const v4i *>(tb + s * 1024);
-        __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);
-        if (late && i > 0 && !(PS_HM_DEBUG & 1)) epilogue(acc_prev, i - 1);
-        v16i acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if (PS_HM_DEBUG & 8) acc[s & 15] += av[s][0] ^ bq[s][1];
-            else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[s], bq[s], acc, 0, 0, 0);
-        }
+            for (int u = 0; u < IT; ++u) {
+                if (PS_HM_DEBUG & 8) acc[u][s & 15] += (float)(av[u][s][0] ^ bq[s][1]);
+                else acc[u] = sign_mfma(av[u][s], bq[s], acc[u]);
+            }
         if (PS_HM_DEBUG & 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_prev[r] ^= acc[r];      // keep the work alive
-        } else if (!late) epilogue(acc, i);
-        else acc_prev = acc;
+            for (int u = 0; u < IT; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_prev[0][r] += acc[u][r];     // keep the work alive
+        } else if (!late) {
+#pragma unroll
+            for (int u = 0; u < IT; ++u) epilogue(acc[u], i * IT + u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < IT; ++u) acc_prev[u] = acc[u];
+        }
         buf = buf + 1 < NBUF ? buf + 1 : 0;
     }
-    if (late && nt > 0 && !(PS_HM_DEBUG & 1)) epilogue(acc_prev, nt - 1);
-    if (PS_HM_DEBUG & 1) { if (max16(acc_prev) == 12345678) cnt = 1; }
+    if (late && nt > 0 && !(PS_HM_DEBUG & 1)) {
+#pragma unroll
+        for (int u = 0; u < IT; ++u) epilogue(acc_prev[u], (nt - 1) * IT + u);
+    }
+    if (PS_HM_DEBUG & 1) { if (max16(acc_prev[0]) == 12345678.f) cnt = 1; }
 
     // ---- results ----
     if (MODE == 0) {
         if (q_ok) {
             int32_t *dst = a.bl + ((int64_t)q * (a.slices * 2) + slice * 2 + lh) * KM;
 #pragma unroll
-            for (int j = 0; j < KM; ++j) dst[j] = best[j] == NO_DOT ? 0x7fffffff : (a.nbits - best[j]) >> 1;
+            for (int j = 0; j < KM; ++j) dst[j] = best[j] == NO_DOT ? 0x7fffffff : (a.nbits - (int)best[j]) >> 1;
         }
         return;
     }
@@ -411,8 +451,9 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     Plan p{};
     p.ok = false;
     if (cs % 4 != 0) return p;
-    p.KS = cs / 4;
-    if (!(p.KS == 1 || p.KS == 2 || p.KS == 4 || p.KS == 8 || p.KS == 16)) return p;
+    if (cs % 8 != 0) return p;
+    p.KS = cs / 8;                                         // 64-bit K steps
+    if (!(p.KS == 1 || p.KS == 2 || p.KS == 4 || p.KS == 8)) return p;
     if (k <= 0 || k > 32) return p;
     if (nq < 64 || N < 4096) return p;                    // small problems: the popcount kernel has no tile padding
     p.km = k <= 16 ? 16 : 32;
@@ -427,7 +468,7 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     while (s > 1 && p.tiles / s < 32) --s;                 // a slice is at least 32 tiles (1024 items)
     const int64_t cap_tiles = ((int64_t)1 << p.shift) >> 5;
     if (p.tiles > s * cap_tiles) s = (p.tiles + cap_tiles - 1) / cap_tiles;   // slice-local ids must fit under the distance bits
-    p.tiles_per_slice = (p.tiles + s - 1) / s;
+    p.tiles_per_slice = ((p.tiles + s - 1) / s + IT - 1) / IT * IT;
     p.slices = (int)((p.tiles + p.tiles_per_slice - 1) / p.tiles_per_slice);
     if (p.slices > 16) return p;                           // merge fan-in: one list per slice, 16 lanes per query
     // bound pass: 1/5 of the table (measured on MI355X, 10 000 x 59 047 x 512 bit: 5 % 0.67 ms, 10 % 0.48, 20 % 0.44,
@@ -441,7 +482,7 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     if (bs < 1) bs = 1;
     if (bs > 8) bs = 8;                                    // <= 16 lists of KM <= 32 values per query (bound_select: 512)
     while (bs > 1 && st / bs < 16) --bs;
-    p.btiles_per_slice = (st + bs - 1) / bs;
+    p.btiles_per_slice = ((st + bs - 1) / bs + IT - 1) / IT * IT;
     p.bslices = (int)((st + p.btiles_per_slice - 1) / p.btiles_per_slice);
     p.sample_tiles = st;
     size_t off = 0;
@@ -464,7 +505,7 @@ bool allow_lds(K kernel, size_t bytes) {
 
 template <int KS>
 int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t *bl, int64_t nq) {
-    const size_t tiles_lds = (size_t)NBUF * KS * 1024;
+    const size_t tiles_lds = (size_t)NBUF * IT * KS * 1024;
     const size_t lds = tiles_lds + (size_t)WAVES * CAP * 64 * sizeof(uint32_t);
     static const bool lds_ok = allow_lds(hamming_mfma_kernel<KS, 0, 16>, 160 * 1024) &&
                                allow_lds(hamming_mfma_kernel<KS, 0, 32>, 160 * 1024) &&
@@ -494,18 +535,18 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
 }  // namespace
 
 extern "C" size_t ps_lsh_planes_bytes(int64_t n, int cs) {
-    if (n <= 0 || cs <= 0 || cs % 4 != 0) return 0;
-    return (size_t)((n + 31) / 32) * (size_t)(cs / 4) * 1024;
+    if (n <= 0 || cs <= 0 || cs % 8 != 0) return 0;
+    return (size_t)(((n + 31) / 32 + IT - 1) / IT * IT) * (size_t)(cs / 8) * 1024;        // whole ring entries
 }
 
 extern "C" int ps_lsh_expand(const uint8_t *codes, int64_t n, int cs, void *planes, ps_stream_t stream) {
     if (n < 0 || cs <= 0) return PS_EINVAL;
-    if (cs % 4 != 0) return PS_EUNSUPPORTED;
+    if (cs % 8 != 0) return PS_EUNSUPPORTED;
     if (n == 0) return PS_OK;
     if (!codes || !planes || reinterpret_cast<size_t>(codes) % 4 != 0 || reinterpret_cast<size_t>(planes) % 16 != 0)
         return PS_EINVAL;
-    const int KS = cs / 4;
-    const int64_t pieces = ((n + 31) / 32) * KS * 64;
+    const int KS = cs / 8;
+    const int64_t pieces = (((n + 31) / 32 + IT - 1) / IT * IT) * KS * 64;                  // padding tiles are zero-filled
     int64_t grid = ps_cdiv(pieces, 256);
     if (grid > 256 * 64) grid = 256 * 64;
     hipLaunchKernelGGL(lsh_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ps_stream(stream),
@@ -546,7 +587,6 @@ extern "C" int ps_hamming_topk_mfma(const void *qplanes, int64_t nq, const void 
         case 2: rc = launch_passes<2>(p, a, st, thr0, bl, nq); break;
         case 4: rc = launch_passes<4>(p, a, st, thr0, bl, nq); break;
         case 8: rc = launch_passes<8>(p, a, st, thr0, bl, nq); break;
-        case 16: rc = launch_passes<16>(p, a, st, thr0, bl, nq); break;
         default: return PS_EUNSUPPORTED;
     }
     if (rc != PS_OK) return rc;

@@ -1,4 +1,4 @@
-"""The int8-MFMA Hamming scan (csrc/hamming_mfma.hip: ps_lsh_expand + ps_hamming_topk_mfma) vs the C oracle's
+"""The MFMA Hamming scan (fp4 sign planes, csrc/hamming_mfma.hip: ps_lsh_expand + ps_hamming_topk_mfma) vs the C oracle's
 restatement of faiss' hammings_knn_hc (reference utils/nearest_neighbors.py:47-68) and vs the popcount kernel:
 (distance, id) lists must be bit-identical -- same distances, same ids, same tie order, same padding.
 
@@ -29,21 +29,23 @@ def _codes(rs, n, cs, kind):
 
 
 def test_sign_planes_layout():
-    """planes[(tile*KS + s)*1024 + lane*16 + j] = +1/-1 for bit 32 s + 16 (lane >> 5) + j of code 32 tile + (lane & 31);
-    rows past the end are zero bytes (they contribute nothing to a dot product)."""
+    """planes[(tile*KS + s)*1024 + lane*16 ..]: the 32 nibbles (low nibble first) of bits 64 s + 32 (lane >> 5) + j of
+    code 32 tile + (lane & 31), +1 = 0x2 / -1 = 0xA in fp4 e2m1; rows past the end are zero nibbles (they contribute
+    nothing to a dot product)."""
     from pinsage_hip import dense
     rs = np.random.RandomState(0)
     n, cs = 77, 16
     codes = rs.randint(0, 256, size=(n, cs)).astype(np.uint8)
-    pl = dense.lsh_expand(torch.from_numpy(codes).cuda()).cpu().numpy().view(np.int8)
-    KS, tiles = cs // 4, (n + 31) // 32
+    pl = dense.lsh_expand(torch.from_numpy(codes).cuda()).cpu().numpy()
+    KS, tiles = cs // 8, ((n + 31) // 32 + 1) // 2 * 2            # padded to whole ring entries of two tiles
     assert pl.size == tiles * KS * 1024
-    pl = pl.reshape(tiles, KS, 64, 16)
+    nib = np.stack([pl & 15, pl >> 4], axis=-1).reshape(tiles, KS, 64, 32)          # low nibble first
     bits = np.unpackbits(codes, axis=1, bitorder="little")      # bit j of the code, LSB-first bytes (faiss)
-    want = np.zeros((tiles * 32, cs * 8), dtype=np.int8)
-    want[:n] = bits.astype(np.int8) * 2 - 1
-    want = want.reshape(tiles, 32, KS, 2, 16).transpose(0, 2, 3, 1, 4).reshape(tiles, KS, 64, 16)
-    assert np.array_equal(pl, want)
+    want = np.zeros((tiles * 32, cs * 8), dtype=np.uint8)
+    want[:n] = np.where(bits == 1, 0x2, 0xA)
+    want = want.reshape(tiles, 32, KS, 2, 32).transpose(0, 2, 3, 1, 4).reshape(tiles, KS, 64, 32)
+    assert np.array_equal(nib, want)
+    assert dense.lsh_expand(torch.zeros((8, 4), dtype=torch.uint8).cuda()) is None   # 32-bit codes: popcount scan only
 
 
 @pytest.mark.parametrize("cs,kind,N,nq,k", [
@@ -67,7 +69,7 @@ def test_mfma_scan_matches_oracle_and_popcount(cs, kind, N, nq, k):
     q[0] = codes[7]
     q[1:nq // 2] ^= rs.randint(0, 256, size=(nq // 2 - 1, cs)).astype(np.uint8) & rs.randint(0, 2, size=(nq // 2 - 1, cs)).astype(np.uint8)
     ct, qt = torch.from_numpy(codes).cuda(), torch.from_numpy(q).cuda()
-    assert dense.hamming_mfma_supported(nq, N, cs, k)
+    assert dense.hamming_mfma_supported(nq, N, cs, k) == (cs >= 8)       # 32-bit codes fall back to the popcount scan
     planes = dense.lsh_expand(ct)
     dm, im = dense.hamming_topk(qt, ct, k, planes=planes)
     dv, iv = dense.hamming_topk(qt, ct, k, use_mfma=False)
