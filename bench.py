@@ -31,9 +31,10 @@ import torch.distributed as dist
 
 HBM_PEAK = 8.0e12          # B/s, spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, v_mfma_f32_32x32x2_f32
-# v_mfma_i32_32x32x32_i8: 2 x the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores) = 65 536 ops per 32 cycles per
-# SIMD; 1024 SIMDs at 2.4 GHz
-MFMA_I8_PEAK = 1024 * 65536 / 32 * 2.4e9
+# v_mfma_scale_f32_32x32x64_f8f6f4 with fp4 operands: 4 x the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores) =
+# 131 072 ops per 32 cycles per SIMD; 1024 SIMDs at 2.4 GHz = 10.07 POP/s dense (tools/ubench/mfma_fp4_probe.hip measures
+# 8.4 POP/s for a bare register-resident loop on random signs)
+MFMA_FP4_PEAK = 1024 * 131072 / 32 * 2.4e9
 # popcount scan (fallback path): SURVEY 8(d)'s bound, wave64 VALU at 2 clocks per instruction (SIMD-32): one v_xor + one
 # v_bcnt per 32-bit word and 64 pairs = 256 B of logical code bytes per 4 clocks per SIMD
 VALU_POPCNT_PEAK = 1024 * 256 / 4 * 2.4e9
@@ -262,9 +263,9 @@ def main():
         if "ps_lsh_encode" in ksum:
             rows = (n_loc + nq_local) / 2.0                      # two launches per step: index + queries
             add("ps_lsh_encode", "mfma", enc_flops * rows, MFMA_F32_PEAK)
-        # Hamming scan as an exact int8 contraction: 2 * nq * N * nbits integer ops (dot = nbits - 2 * hamming); the C-ABI
-        # call covers the bound pass (1/5 of the table again), the collect pass and the slice merge
-        add("ps_hamming_topk_mfma", "mfma", 2.0 * nq * n_loc * nbits, MFMA_I8_PEAK)
+        # Hamming scan as an exact +-1 contraction on fp4 MFMA: 2 * nq * N * nbits sign operations (dot = nbits - 2 *
+        # hamming); the C-ABI call covers the bound pass (1/5 of the table again), the collect pass and the slice merge
+        add("ps_hamming_topk_mfma", "mfma", 2.0 * nq * n_loc * nbits, MFMA_FP4_PEAK)
         # popcount fallback (shapes the MFMA path does not serve): VALU bound on the logical code bytes
         add("ps_hamming_topk", "valu", float(nq) * n_loc * (nbits // 8), VALU_POPCNT_PEAK)
         if "ps_mt19937_random_sample" in ksum:                    # numpy-stream mode: 8 B written per uniform
@@ -284,7 +285,7 @@ def main():
                     "unit": unit, "frac": kd["frac"],
                     "traffic": traffic.get(dom), "traffic_source": traffic.get("source") if dom in traffic else None,
                     "avg_launch_ms": kd["avg_ms"], "algorithmic_per_launch": kd["achieved"] * kd["avg_ms"] * 1e-3,
-                    "note": {"ps_hamming_topk_mfma": "exact int8 MFMA contraction; peak = dense i8 (2 x bf16 per clock at 2.4 GHz); "
+                    "note": {"ps_hamming_topk_mfma": "exact +-1 contraction on fp4 MFMA; peak = dense fp4 (4 x bf16 per clock at 2.4 GHz); "
                                                      "the call includes the bound pass over 1/5 of the table, counted as overhead",
                              "ps_walk_sample_layers": "algorithmic bytes per SURVEY 8(d) (rowptr pair + log2(deg) CDF probes + col "
                                                       "[+ uniform] per taken step), both layers of a start node in one launch"}.get(dom)}
@@ -315,7 +316,7 @@ def main():
             "metric": "item embeddings/sec + top-K ANN queries/sec, ML-25M d=256, 1/2/4/8 GPU",
             "value": value, "unit": "items/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64 cdf / f32 features / i8 sign planes (exact integer Hamming)", "data": "synthetic",
+            "dtype": "f64 cdf / f32 features / fp4 sign planes (exact integer Hamming)", "data": "synthetic",
             "config": {"workload": f"SYN-25M (ML-25M-shaped: U={U} M={M} R={R}), F=128 H=256 d={D}, 2 GCN layers, "
                                    f"W=100 L=2 T={T}, LSH {nbits}-bit, {nq} queries K={a.k}, rng={a.rng}"
                                    + (" (the reference's np.random MT19937 stream generated on device: neighbour ids bit-exact with "

@@ -255,10 +255,15 @@ class PinSage(nn.Module):
         n = x.size(0)
         if hasattr(random_walk_sampler, "sample_batches"):
             # every layer's fresh sample of nodes 0..n-1 in one launch, same draws in the same order (:271-275)
-            for batch in random_walk_sampler.sample_batches(range(n), num_neighbors, self.num_layers):
-                all_neighbors.append(sampling.LazyNeighborList(batch, "ids"))
-                all_weights.append(sampling.LazyNeighborList(batch, "weights"))
-            return self.forward(x, edge_index=None, sampled_neighbors=all_neighbors, importance_weights=all_weights)
+            # the np.random state hand-back of the numpy-stream mode completes AFTER the forward pass has been enqueued
+            # (the host does not wait for the stream generator before launching the kernels that follow it)
+            try:
+                for batch in random_walk_sampler.sample_batches(range(n), num_neighbors, self.num_layers, defer_state=True):
+                    all_neighbors.append(sampling.LazyNeighborList(batch, "ids"))
+                    all_weights.append(sampling.LazyNeighborList(batch, "weights"))
+                return self.forward(x, edge_index=None, sampled_neighbors=all_neighbors, importance_weights=all_weights)
+            finally:
+                dense.finish_rng_state()
         for _ in range(self.num_layers):
             if hasattr(random_walk_sampler, "sample_batch"):
                 nodes = torch.arange(n, dtype=torch.int64, device=random_walk_sampler.graph.device)

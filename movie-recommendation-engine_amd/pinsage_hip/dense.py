@@ -204,10 +204,27 @@ def _radix_polys(dev):
     return _radix_polys_dev[key]
 
 
+_pending_state = []
+
+
+def finish_rng_state():
+    """Completes a deferred hand-back of the np.random state (mt19937_random_sample(advance='defer')): waits for the
+    624-word state copy (an event, not a device synchronisation) and installs it with np.random.set_state.  Called by
+    the code that asked for the deferral before it returns to the caller, so user code always sees the advanced state."""
+    import numpy as np
+    while _pending_state:
+        name, has_gauss, cached, host_state, host_pos, ev = _pending_state.pop()
+        ev.synchronize()
+        np.random.set_state((name, host_state.numpy().view(np.uint32).copy(), int(host_pos.item()), has_gauss, cached))
+
+
 def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=True):
     """n doubles of the process-global numpy legacy stream generated ON THE DEVICE (after skipping `skip`
     doubles); with advance=True the global np.random state is advanced exactly as
-    `np.random.random_sample(skip + n)` would (reference utils/random_walk.py:79 draws these one at a time)."""
+    `np.random.random_sample(skip + n)` would (reference utils/random_walk.py:79 draws these one at a time).
+    advance='defer': the state comes back through an asynchronous copy that `finish_rng_state()` completes -- the host
+    keeps enqueueing the kernels that consume the uniforms instead of waiting for the generator (the caller must call
+    finish_rng_state() before returning to code that may touch np.random)."""
     import numpy as np
     name, key, pos, has_gauss, cached = np.random.get_state()
     if name != "MT19937":
@@ -227,7 +244,17 @@ def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=
                 nv.ptr(out), nv.ptr(st_out), nv.ptr(pos_out), nv.ptr(polys),
                 nv.i32(int(polys.size(0)) if polys is not None else 0), nv.ptr(rpolys),
                 nv.i32(int(rpolys.size(0)) if rpolys is not None else 0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
-    if advance:
+    if advance == "defer":
+        finish_rng_state()                                           # at most one hand-back in flight
+        host_state = torch.empty(624, dtype=torch.int32).pin_memory()
+        host_pos = torch.empty(1, dtype=torch.int32).pin_memory()
+        with torch.cuda.device(dev):
+            host_state.copy_(st_out, non_blocking=True)
+            host_pos.copy_(pos_out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        _pending_state.append((name, has_gauss, cached, host_state, host_pos, ev))
+    elif advance:
         new_key = st_out.cpu().numpy().view(np.uint32)
         np.random.set_state((name, new_key, int(pos_out.item()), has_gauss, cached))
     return out

@@ -107,12 +107,13 @@ def _nodes_tensor(nodes, device, num_nodes):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
-def draw_numpy_uniforms(n, device):
+def draw_numpy_uniforms(n, device, defer_state=False):
     """n doubles of the process-global legacy numpy stream, exactly what n sequential
-    `np.random.choice(..., p=...)` calls consume (utils/random_walk.py:79), staged to HBM."""
+    `np.random.choice(..., p=...)` calls consume (utils/random_walk.py:79), staged to HBM.
+    defer_state: see dense.mt19937_random_sample(advance='defer')."""
     if n >= (1 << 17):
         from . import dense                    # same stream, generated on the device (jump-ahead chunks)
-        return dense.mt19937_random_sample(int(n), device)
+        return dense.mt19937_random_sample(int(n), device, advance="defer" if defer_state else True)
     u = np.random.random_sample(int(n))
     t = torch.from_numpy(u)
     if n:
@@ -174,12 +175,13 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
 
 
 def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None,
-                       stream_nodes=None):
+                       stream_nodes=None, defer_state=False):
     """`layers` consecutive batch_sample_neighbors calls over the same start nodes (PinSage.get_embeddings,
     model/pinsage.py:271-275) as ONE kernel launch (ps_walk_sample_layers) -> list of NeighborBatch.  Bit-identical
     to `layers` walk_sample calls: Philox uses call, call + 1, ...; rng='numpy' draws all layers' uniforms from the
     global stream in one go (layer 0's, then layer 1's, ... as the reference consumes them) and hands the state back
-    once.  `nodes` may be a python range (no host sync in the steady state)."""
+    once.  `nodes` may be a python range (no host sync in the steady state).  defer_state=True leaves that hand-back to
+    dense.finish_rng_state(), which the caller must invoke before it returns to user code."""
     dev = graph.device
     as_range = nodes if isinstance(nodes, range) else None
     if as_range is not None:
@@ -218,7 +220,7 @@ def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0,
                     cache[key] = (uoff_all, stride)
             uoff = uoff_all if stream_nodes is None else uoff_all[lo:lo + B].contiguous()
             if uniforms is None:
-                uniforms = draw_numpy_uniforms(layers * stride, dev)
+                uniforms = draw_numpy_uniforms(layers * stride, dev, defer_state=defer_state)
             mode = nv.PS_RNG_STREAM
         elif rng == "philox":
             uoff, uniforms, mode = None, None, nv.PS_RNG_PHILOX

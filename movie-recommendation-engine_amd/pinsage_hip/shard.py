@@ -101,7 +101,11 @@ class HipOps:
         stream = None
         if shard is not None and getattr(sampler, "rng", None) == "numpy":
             stream = (range(shard[0]), shard[1])
-        return sampler.sample_batches(range(lo, hi), T, layers, stream_nodes=stream)
+        return sampler.sample_batches(range(lo, hi), T, layers, stream_nodes=stream, defer_state=True)
+
+    def finish(self):
+        """completes the deferred np.random state hand-back of sample_layers (numpy-stream mode)"""
+        dense.finish_rng_state()
 
     def pool(self, h_full, batch, max_idx):
         return sampling.importance_pool(h_full, batch, max_idx=max_idx)
@@ -168,6 +172,13 @@ class ShardedPinSage:
     def embed(self, x_local, T, x_full=None):
         """x_local: this rank's feature rows.  x_full (optional, replicated [M, F] features): layer-0 hidden
         rows of ALL items are then recomputed locally (one small GEMM) instead of all-gathered."""
+        try:
+            return self._embed(x_local, T, x_full)
+        finally:
+            if hasattr(self.ops, "finish"):
+                self.ops.finish()                # np.random state of the numpy-stream mode, after everything is enqueued
+
+    def _embed(self, x_local, T, x_full=None):
         ops, P = self.ops, self.P
         dev = x_local.device
         nodes = torch.arange(self.lo, self.hi, dtype=torch.int64, device=dev)

@@ -68,7 +68,7 @@ class RandomWalkSampler:
                                     rng=self.rng, seed=self.seed, call=call, uniforms=uniforms,
                                     stream_nodes=stream_nodes if self.rng == "numpy" else None)
 
-    def sample_batches(self, nodes, num_neighbors=10, layers=2, stream_nodes=None):
+    def sample_batches(self, nodes, num_neighbors=10, layers=2, stream_nodes=None, defer_state=False):
         """`layers` consecutive sample_batch calls over the same nodes in ONE launch (what PinSage.get_embeddings
         needs, model/pinsage.py:271-275) -> list of NeighborBatch, identical to calling sample_batch `layers` times.
         `nodes` may be a python range."""
@@ -76,7 +76,8 @@ class RandomWalkSampler:
         self._calls += layers
         return sampling.walk_sample_layers(self.graph, nodes, int(num_neighbors), int(layers), W=self.num_walks,
                                            L=self.walk_length, rng=self.rng, seed=self.seed, call=call,
-                                           stream_nodes=stream_nodes if self.rng == "numpy" else None)
+                                           stream_nodes=stream_nodes if self.rng == "numpy" else None,
+                                           defer_state=defer_state)
 
     def single_walks(self, start_nodes):
         """Batched _single_walk: int32[B, walk_length] device tensor (-1 after a sink)."""

@@ -370,7 +370,9 @@ def test_fused_layer_sampling_equals_separate_calls(W, L, T, layers):
         lo, hi = 700, 1900
         np.random.seed(123)
         d = RandomWalkSampler.from_graph(a.graph, walk_length=L, num_walks=W, rng=rng, seed=9)   # Philox call counter at 0
-        part = HipOps().sample_layers(d, lo, hi, T, layers, shard=(M, lo))
+        ops = HipOps()
+        part = ops.sample_layers(d, lo, hi, T, layers, shard=(M, lo))
+        ops.finish()                                             # the deferred np.random state hand-back (numpy mode)
         assert np.random.random_sample() == tail or rng == "philox"
         for f, s in zip(part, sep):
             assert torch.equal(f.ids, s.ids[lo:hi]) and torch.equal(f.counts, s.counts[lo:hi])
