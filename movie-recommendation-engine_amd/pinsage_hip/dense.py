@@ -79,6 +79,10 @@ def lsh_encode(x, A):
     return codes
 
 
+HAMMING_MAX_K = 64        # ps_hamming_topk (popcount scan); the MFMA scan serves k <= 32 and falls back above
+DOT_L2_MAX_K = 160        # ps_dot_topk / ps_l2_topk
+
+
 def lsh_expand(codes):
     """Sign planes of a code table (uint8 [n, cs] -> +1/-1 bytes in MFMA fragment order, see csrc/hamming_mfma.hip);
     None when the code size is not a multiple of 4 bytes."""
@@ -108,6 +112,9 @@ def hamming_topk(qcodes, codes, k, id_offset=0, planes=None, use_mfma=True):
     codes = codes.contiguous()
     nq, cs = int(qcodes.size(0)), int(qcodes.size(1))
     N = int(codes.size(0))
+    if k > HAMMING_MAX_K:
+        raise ValueError(f"LSH search supports k <= {HAMMING_MAX_K} (a query's k best keys live across the 64 lanes of a "
+                         f"wave); got k = {k}.  faiss accepts any k: split the request or use the exact search")
     dist = torch.empty((nq, k), dtype=torch.int32, device=qcodes.device)
     ids = torch.empty((nq, k), dtype=torch.int64, device=qcodes.device)
     L = nv.lib()
@@ -149,6 +156,8 @@ def dot_topk(E, qidx, k, exclude_self=True):
     qidx = qidx.to(device=E.device, dtype=torch.int64).contiguous()
     N, D = int(E.size(0)), int(E.size(1))
     nq = int(qidx.numel())
+    if k > DOT_L2_MAX_K:
+        raise ValueError(f"exact search supports k <= {DOT_L2_MAX_K}; got k = {k} (torch.topk in the reference accepts any k)")
     vals = torch.empty((nq, k), dtype=torch.float32, device=E.device)
     ids = torch.empty((nq, k), dtype=torch.int64, device=E.device)
     L = nv.lib()
@@ -167,6 +176,8 @@ def l2_topk(X, Q, k, assign=None, probe=None):
     Q = Q.to(X.device).contiguous()
     N, D = int(X.size(0)), int(X.size(1))
     nq = int(Q.size(0))
+    if k > DOT_L2_MAX_K:
+        raise ValueError(f"L2 / IVF search supports k <= {DOT_L2_MAX_K}; got k = {k} (faiss accepts any k)")
     dist = torch.empty((nq, k), dtype=torch.float32, device=X.device)
     ids = torch.empty((nq, k), dtype=torch.int64, device=X.device)
     L = nv.lib()

@@ -47,7 +47,10 @@ class NeighborBatch:
 
 class LazyNeighborList(list):
     """A real `list` (isinstance checks in the reference pass) whose items are produced from the
-    device batch on first python-level access.  Our own kernels read `.batch` and never touch it."""
+    device batch on first python-level access.  Our own kernels read `.batch` and never touch it.
+    Until then the C-level list holds `None` placeholders of the right length, so consumers that bypass the python
+    protocol (PySequence_Fast: `torch.tensor(lst)`, `np.asarray(lst)` on some paths) fail loudly on a None instead of
+    silently seeing an empty list; `.materialize()` (or any python-level access) fills it."""
 
     EAGER_BELOW = 4096
 
@@ -58,12 +61,19 @@ class LazyNeighborList(list):
         self._done = False
         if batch.B <= self.EAGER_BELOW:       # small batches: a plain, fully populated list (C-level consumers too)
             self._fill()
+        else:
+            super().extend([None] * batch.B)
 
     def _fill(self):
         if not self._done:
             self._done = True
             nb, wt = self.batch.to_lists()
-            super().extend(nb if self.kind == "ids" else wt)
+            list.__setitem__(self, slice(None), nb if self.kind == "ids" else wt)
+
+    def materialize(self):
+        """fill the list now (for code that hands it to C-level consumers)"""
+        self._fill()
+        return self
 
     def __len__(self):
         return self.batch.B

@@ -1,5 +1,5 @@
 """The N>1 orchestration (item-range shards, per-layer all-gather of hidden rows, all-gather +
-merge of top-k candidates) under gloo with world_size 2 on CPU.  The compute backend is swapped for
+merge of top-k candidates) under gloo with world_size 2 and 3 on CPU.  The compute backend is swapped for
 the CPU oracle (allowed: tests only), so what is checked here is that the sharded pipeline's answer is
 identical to the single-shard one -- ids / codes / neighbour ids bit-exact, embeddings to 1e-6."""
 import os
@@ -118,10 +118,11 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_pipeline_equals_single(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])          # 3 ranks: 34 / 34 / 33 items (bench.py was rehearsed with 3 ranks too)
+def test_multi_rank_pipeline_equals_single(tmp_path, world):
     from oracle import c_oracle as co
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_run, args=(world, _free_port(), out), nprocs=world, join=True)
     got = torch.load(out)
     # single-shard reference, straight from the oracle
     cg, params, x, A = _setup()
@@ -134,7 +135,7 @@ def test_two_rank_pipeline_equals_single(tmp_path):
     ref_codes = co.lsh_encode(got["emb"].numpy(), A.numpy())
     assert np.array_equal(got["codes"].numpy(), ref_codes)
     chunk = got["chunk"]
-    qrows = np.concatenate([np.arange(8), chunk + np.arange(8)])          # rank-major query order
+    qrows = np.concatenate([r * chunk + np.arange(8) for r in range(world)])   # rank-major query order
     rd, ri = co.hamming_topk(ref_codes[qrows], ref_codes, K)
     assert np.array_equal(got["i"].numpy(), ri)
     assert np.array_equal(got["d"].numpy(), rd.astype(np.int32))

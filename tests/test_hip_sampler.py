@@ -234,8 +234,8 @@ def test_error_paths_raise_loudly():
     idx.build(torch.randn(10, 16))
     with pytest.raises(AssertionError):
         idx.search(torch.randn(2, 15), 3)                           # wrong dimensionality
-    with pytest.raises(native.NativeError, match="unsupported"):
-        idx.search(torch.randn(2, 16), 100)                         # k > 64
+    with pytest.raises(ValueError, match="k <= 64"):
+        idx.search(torch.randn(2, 16), 100)                         # k > 64: the limit is named
 
 
 def test_hard_negatives_match_reference_semantics():

@@ -30,6 +30,12 @@ def test_lazy_neighbor_list_is_a_list():
     assert isinstance(nb, list) and len(nb) == 3 and nb._done and list.__len__(nb) == 3     # small: eager
     LazyNeighborList.EAGER_BELOW = 0
     lazy = LazyNeighborList(b, "ids")
+    # not filled yet: the C-level list holds None placeholders of the right length (a consumer that bypasses the python
+    # protocol fails loudly instead of seeing an empty list)
+    assert not lazy._done and list.__len__(lazy) == 3 and list.__getitem__(lazy, 0) is None
+    with pytest.raises((TypeError, ValueError, RuntimeError)):
+        torch.tensor(LazyNeighborList(b, "ids"))
+    assert LazyNeighborList(b, "weights").materialize()[1] == [1.0]
     assert not lazy._done and len(lazy) == 3 and [len(r) for r in lazy] == [2, 1, 0] and lazy._done
     LazyNeighborList.EAGER_BELOW = 4096
     assert [list(map(int, r)) for r in nb] == [[4, 9], [7], []]
