@@ -268,8 +268,9 @@ def main():
         add("ps_hamming_topk_mfma", "mfma", 2.0 * nq * n_loc * nbits, MFMA_FP4_PEAK)
         # popcount fallback (shapes the MFMA path does not serve): VALU bound on the logical code bytes
         add("ps_hamming_topk", "valu", float(nq) * n_loc * (nbits // 8), VALU_POPCNT_PEAK)
-        if "ps_mt19937_random_sample" in ksum:                    # numpy-stream mode: 8 B written per uniform
-            add("ps_mt19937_random_sample", "hbm", 8.0 * (steps0 + steps1), HBM_PEAK)
+        for mt_call in ("ps_mt19937_raw_stream", "ps_mt19937_random_sample"):     # numpy-stream mode: 8 B written per uniform
+            if mt_call in ksum:
+                add(mt_call, "hbm", 8.0 * (steps0 + steps1), HBM_PEAK)
         try:
             traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
         except Exception:
@@ -298,7 +299,8 @@ def main():
                    "ps_hamming_topk_mfma": ["hamming_mfma_kernel<KS,0,16> (bound)", "bound_select_kernel",
                                             "hamming_mfma_kernel<KS,1,16> (collect)", "slice_merge_kernel"],
                    "ps_hamming_topk": ["hamming_scan_kernel<16,4>", "topk_rank_merge_kernel"],
-                   "ps_mt19937_random_sample": ["mt_* (jump-ahead windows + chunk generators)"]}
+                   "ps_mt19937_raw_stream": ["mt_prepare", "2 x (mt_expand + mt_combine_radix)", "mt_chunk", "mt_final_state"],
+                   "ps_mt19937_random_sample": ["mt_* (jump-ahead windows + chunk generators + mt_raw_to_double)"]}
         for n, k in kern.items():
             k["device_kernels"] = symbols.get(n, [])
         if "ps_importance_pool" in kern:

@@ -35,6 +35,8 @@ extern "C" {
 
 #define PS_RNG_STREAM 0     /* uniforms[] holds the numpy legacy MT19937 stream */
 #define PS_RNG_PHILOX 1     /* Philox4x32-10, counter (node, walk, step/2, call): one block = two steps  */
+#define PS_RNG_STREAM_RAW 2 /* ps_walk_sample / ps_walk_sample_layers only: `uniforms` holds the stream as raw MT19937 words
+                               (ps_mt19937_raw_stream): uniform i = genrand_res53(temper(word 2i), temper(word 2i+1)) */
 
 typedef void *ps_stream_t;
 
@@ -140,7 +142,13 @@ int ps_uniform_offsets(const int64_t *rowptr, int64_t V, const int64_t *starts, 
  * jump-ahead); with NULL polynomials / workspace a single workgroup generates the stream serially (skip must be 0).
  * radix_polys uint32[radix_levels, 31, 624] (entry (i, j-1) = t^(j * 2^(c + 5i)) mod phi, optional): the chunk windows
  * are then produced in radix-32 rounds instead of by doubling. */
+/* ps_mt19937_raw_stream: the same stream (skip = 0) left as untempered 32-bit state words in raw uint32[2n + 1248] for
+ * PS_RNG_STREAM_RAW -- the walk kernel tempers and combines the two words of a uniform itself, which saves the conversion
+ * pass (65 us and 190 MB of traffic per 23.6 M doubles).  Needs the jump polynomials (n >= 2^17). */
 int ps_mt19937_chunk_log2(void);
+int ps_mt19937_raw_stream(const uint32_t *state_in, int pos_in, int64_t n, uint32_t *raw, uint32_t *state_out,
+                          int32_t *pos_out, const uint32_t *jump_polys, int jump_levels, const uint32_t *radix_polys,
+                          int radix_levels, void *workspace, size_t workspace_bytes, ps_stream_t stream);
 size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n);
 int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,
                              uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys, int jump_levels,

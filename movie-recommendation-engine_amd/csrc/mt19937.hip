@@ -265,6 +265,28 @@ Plan make_plan(int pos_in, int64_t skip, int64_t n) {
 
 extern "C" int ps_mt19937_chunk_log2(void) { return CHUNK_LOG2; }
 
+static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out, uint32_t *raw_out,
+                       uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys, int jump_levels,
+                       const uint32_t *radix_polys, int radix_levels, void *workspace, size_t workspace_bytes,
+                       ps_stream_t stream);
+
+extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,
+                                        uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys,
+                                        int jump_levels, const uint32_t *radix_polys, int radix_levels, void *workspace,
+                                        size_t workspace_bytes, ps_stream_t stream) {
+    return mt_generate(state_in, pos_in, skip, n, out, nullptr, state_out, pos_out, jump_polys, jump_levels, radix_polys,
+                       radix_levels, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ps_mt19937_raw_stream(const uint32_t *state_in, int pos_in, int64_t n, uint32_t *raw, uint32_t *state_out,
+                                     int32_t *pos_out, const uint32_t *jump_polys, int jump_levels,
+                                     const uint32_t *radix_polys, int radix_levels, void *workspace, size_t workspace_bytes,
+                                     ps_stream_t stream) {
+    if (!raw || !jump_polys || !workspace || n < (1 << 17)) return PS_EINVAL;
+    return mt_generate(state_in, pos_in, 0, n, nullptr, raw, state_out, pos_out, jump_polys, jump_levels, radix_polys,
+                       radix_levels, workspace, workspace_bytes, stream);
+}
+
 extern "C" size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n) {
     if (n < 0 || skip < 0) return 0;
     const Plan p = make_plan(MT_N, skip, n);            // pos only shifts the plan by < 624 words
@@ -274,12 +296,12 @@ extern "C" size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n) {
     return states + seqs + align256((size_t)(p.w_hi - p.w_lo + 2 * MT_N + CHUNK) * 4) + 4096;
 }
 
-extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,
-                                        uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys,
-                                        int jump_levels, const uint32_t *radix_polys, int radix_levels, void *workspace,
-                                        size_t workspace_bytes, ps_stream_t stream) {
+static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out, uint32_t *raw_out,
+                       uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys,
+                       int jump_levels, const uint32_t *radix_polys, int radix_levels, void *workspace,
+                       size_t workspace_bytes, ps_stream_t stream) {
     if (!state_in || !state_out || !pos_out || n < 0 || skip < 0 || pos_in < 0 || pos_in > MT_N) return PS_EINVAL;
-    if (n > 0 && !out) return PS_EINVAL;
+    if (n > 0 && !out && !raw_out) return PS_EINVAL;
     hipStream_t st = ps_stream(stream);
     if (n == 0 && skip == 0) {                          // nothing consumed: state unchanged
         if (hipMemcpyAsync(state_out, state_in, MT_N * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
@@ -313,6 +335,10 @@ extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, in
     uint32_t *word0 = tmpB + WSZ;
     uint32_t *seqs = reinterpret_cast<uint32_t *>(base + align256((size_t)(K + 4) * JP * MT_N * 4));
     uint32_t *raw = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(seqs) + align256((size_t)(K / 2 + 2) * SEQ_PAD * 4));
+    if (raw_out) {                                       // raw mode: the chunk generators write straight into the caller's buffer
+        if (p.w_lo != 0) return PS_EUNSUPPORTED;         // (skip = 0: word 2i is the first word of uniform i)
+        raw = raw_out;
+    }
     // 1. W1 (part 0 of tmpA, the other parts zero) and word 0
     if (hipMemsetAsync(tmpA, 0, WSZ * 4, st) != hipSuccess) return PS_ELAUNCH;
     hipLaunchKernelGGL(mt_prepare_kernel, dim3(1), dim3(256), 0, st, state_in, pos_in, tmpA, word0);
@@ -358,8 +384,8 @@ extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, in
     PS_CHECK_LAUNCH();
     if (p.w_lo == 0)
         if (hipMemcpyAsync(raw, word0, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
-    // 5. doubles
-    if (n > 0) {
+    // 5. doubles (raw mode: the consumer tempers and combines)
+    if (n > 0 && !raw_out) {
         int64_t grid = ps_cdiv(n, 256);
         if (grid > 8192) grid = 8192;
         hipLaunchKernelGGL(mt_raw_to_double_kernel, dim3((unsigned)grid), dim3(256), 0, st, raw, p.w_lo, skip, n, out);

@@ -63,6 +63,21 @@ __device__ __forceinline__ void philox_uniform2(uint32_t k0, uint32_t k1, uint32
     u_odd = ((double)(c2 >> 5) * 67108864.0 + (double)(c3 >> 6)) * (1.0 / 9007199254740992.0);
 }
 
+// PS_RNG_STREAM_RAW: the stream as the generator leaves it (untempered MT19937 state words); uniform i = words 2i, 2i+1,
+// tempered and combined like numpy's random_sample (genrand_res53) -- saves the separate conversion pass over the stream
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+__device__ __forceinline__ double stream_uniform(const double *uniforms, int64_t i, bool raw) {
+    if (!raw) return uniforms[i];
+    const uint2 w = reinterpret_cast<const uint2 *>(uniforms)[i];
+    return ((double)(mt_temper(w.x) >> 5) * 67108864.0 + (double)(mt_temper(w.y) >> 6)) * (1.0 / 9007199254740992.0);
+}
+
 __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
     uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
@@ -324,7 +339,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             }
             continue;
         }
-        const int64_t ubase0 = (a.rng_mode == PS_RNG_STREAM) ? uniform_i64(a.uoff[i]) : 0;
+        const bool stream = a.rng_mode != PS_RNG_PHILOX, raw = a.rng_mode == PS_RNG_STREAM_RAW;
+        const int64_t ubase0 = stream ? uniform_i64(a.uoff[i]) : 0;
 
         // ---------------- walk phase: all rounds, the start row is staged once ----------
         for (int j = lane; j < R * NP * 64; j += 64) posb_all[j] = -1;
@@ -359,9 +375,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                 if (hiA == loA) aliveA = false;       // sink: the walk stops (random_walk.py:68-69)
                 if (hiB == loB) aliveB = false;
                 double uA = 2.0, uB = 2.0;
-                if (a.rng_mode == PS_RNG_STREAM) {
-                    if (aliveA) uA = a.uniforms[ubase + (int64_t)wA * a.L + st];
-                    if (aliveB) uB = a.uniforms[ubase + (int64_t)wB * a.L + st];
+                if (stream) {
+                    if (aliveA) uA = stream_uniform(a.uniforms, ubase + (int64_t)wA * a.L + st, raw);
+                    if (aliveB) uB = stream_uniform(a.uniforms, ubase + (int64_t)wB * a.L + st, raw);
                 } else if ((st & 1) == 0) {
                     philox_uniform2(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wA, (uint32_t)(st >> 1), call, uA, uA1);
                     philox_uniform2(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wB, (uint32_t)(st >> 1), call, uB, uB1);
@@ -575,8 +591,8 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
     if (B < 0 || W <= 0 || L <= 0 || T <= 0 || V < 0 || rounds <= 0 || rounds > 8 || round_stride < 0) return PS_EINVAL;
     if (B == 0) return PS_OK;
     if (!rowptr || !col || !cdf || !starts || !ids || !counts || !nvalid) return PS_EINVAL;
-    if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX) return PS_EINVAL;
-    if (rng_mode == PS_RNG_STREAM && (!uniforms || !uoff)) return PS_EINVAL;
+    if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX && rng_mode != PS_RNG_STREAM_RAW) return PS_EINVAL;
+    if (rng_mode != PS_RNG_PHILOX && (!uniforms || !uoff)) return PS_EINVAL;
     if ((nodeinfo == nullptr) != (guide == nullptr)) return PS_EINVAL;
     if (packed && !nodeinfo) return PS_EINVAL;
     if (buckets && (!nodeinfo || reinterpret_cast<size_t>(buckets) % 64 != 0)) return PS_EINVAL;

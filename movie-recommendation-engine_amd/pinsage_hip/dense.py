@@ -229,13 +229,15 @@ def finish_rng_state():
         np.random.set_state((name, host_state.numpy().view(np.uint32).copy(), int(host_pos.item()), has_gauss, cached))
 
 
-def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=True):
+def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=True, raw=False):
     """n doubles of the process-global numpy legacy stream generated ON THE DEVICE (after skipping `skip`
     doubles); with advance=True the global np.random state is advanced exactly as
     `np.random.random_sample(skip + n)` would (reference utils/random_walk.py:79 draws these one at a time).
     advance='defer': the state comes back through an asynchronous copy that `finish_rng_state()` completes -- the host
     keeps enqueueing the kernels that consume the uniforms instead of waiting for the generator (the caller must call
-    finish_rng_state() before returning to code that may touch np.random)."""
+    finish_rng_state() before returning to code that may touch np.random).
+    raw=True (skip = 0, n >= 2^17): returns the stream as untempered MT19937 words, int32[2n + 1248], for the walk kernels'
+    PS_RNG_STREAM_RAW mode (uniform i = words 2i, 2i + 1) instead of doubles."""
     import numpy as np
     name, key, pos, has_gauss, cached = np.random.get_state()
     if name != "MT19937":
@@ -244,14 +246,22 @@ def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=
     st_in = torch.from_numpy(key.astype(np.uint32).view(np.int32)).to(dev)
     st_out = torch.empty(624, dtype=torch.int32, device=dev)
     pos_out = torch.empty(1, dtype=torch.int32, device=dev)
-    out = torch.empty(int(n), dtype=torch.float64, device=dev)
+    if raw and (skip != 0 or not parallel or n < (1 << 17)):
+        raise ValueError("raw stream: skip = 0, the parallel generator and n >= 2^17 are required")
+    out = (torch.empty(2 * int(n) + 1248, dtype=torch.int32, device=dev) if raw else
+           torch.empty(int(n), dtype=torch.float64, device=dev))
     polys = _jump_polys(dev) if parallel else None
     rpolys = _radix_polys(dev) if (parallel and radix) else None      # radix=False: windows by doubling
     L = nv.lib()
     wsb = int(L.ps_mt19937_workspace_bytes(nv.i64(int(skip)), nv.i64(int(n)))) if parallel else 0
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if parallel else None
     with torch.cuda.device(dev):
-        nv.call("ps_mt19937_random_sample", nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(skip)), nv.i64(int(n)),
+        if raw:
+            nv.call("ps_mt19937_raw_stream", nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(n)), nv.ptr(out), nv.ptr(st_out),
+                    nv.ptr(pos_out), nv.ptr(polys), nv.i32(int(polys.size(0))), nv.ptr(rpolys),
+                    nv.i32(int(rpolys.size(0)) if rpolys is not None else 0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
+        else:
+          nv.call("ps_mt19937_random_sample", nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(skip)), nv.i64(int(n)),
                 nv.ptr(out), nv.ptr(st_out), nv.ptr(pos_out), nv.ptr(polys),
                 nv.i32(int(polys.size(0)) if polys is not None else 0), nv.ptr(rpolys),
                 nv.i32(int(rpolys.size(0)) if rpolys is not None else 0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())

@@ -117,13 +117,17 @@ def _nodes_tensor(nodes, device, num_nodes):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
-def draw_numpy_uniforms(n, device, defer_state=False):
+def draw_numpy_uniforms(n, device, defer_state=False, raw=False):
     """n doubles of the process-global legacy numpy stream, exactly what n sequential
     `np.random.choice(..., p=...)` calls consume (utils/random_walk.py:79), staged to HBM.
-    defer_state: see dense.mt19937_random_sample(advance='defer')."""
+    defer_state: see dense.mt19937_random_sample(advance='defer').  raw=True: the caller can consume the stream as raw
+    MT19937 words (PS_RNG_STREAM_RAW); returns (tensor, is_raw) -- short requests are drawn on the host as doubles."""
     if n >= (1 << 17):
         from . import dense                    # same stream, generated on the device (jump-ahead chunks)
-        return dense.mt19937_random_sample(int(n), device, advance="defer" if defer_state else True)
+        t = dense.mt19937_random_sample(int(n), device, advance="defer" if defer_state else True, raw=raw)
+        return (t, True) if raw else t
+    if raw:
+        return draw_numpy_uniforms(n, device, defer_state), False
     u = np.random.random_sample(int(n))
     t = torch.from_numpy(u)
     if n:
@@ -229,9 +233,10 @@ def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0,
                 if key is not None:
                     cache[key] = (uoff_all, stride)
             uoff = uoff_all if stream_nodes is None else uoff_all[lo:lo + B].contiguous()
-            if uniforms is None:
-                uniforms = draw_numpy_uniforms(layers * stride, dev, defer_state=defer_state)
             mode = nv.PS_RNG_STREAM
+            if uniforms is None:
+                uniforms, is_raw = draw_numpy_uniforms(layers * stride, dev, defer_state=defer_state, raw=True)
+                mode = nv.PS_RNG_STREAM_RAW if is_raw else nv.PS_RNG_STREAM
         elif rng == "philox":
             uoff, uniforms, mode = None, None, nv.PS_RNG_PHILOX
         else:

@@ -55,6 +55,8 @@ out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, ben
        "ps_walk_sample_layers": per_launch(lambda k: k.startswith("walk_sample_kernel")),
        "ps_hamming_topk_mfma": per_launch(lambda k: k.startswith("hamming_mfma_kernel") or k.startswith("bound_select_kernel")
                                           or k.startswith("slice_merge_kernel")),
+       "ps_mt19937_raw_stream": per_launch(lambda k: k.startswith("mt_chunk_kernel") or k.startswith("mt_final_state") or k.startswith("mt_prepare")) +
+                                2 * per_launch(lambda k: k.startswith("mt_combine_radix") or k.startswith("mt_expand")),
        "ps_mt19937_random_sample": per_launch(lambda k: k.startswith("mt_chunk_kernel") or k.startswith("mt_raw_to_double")
                                               or k.startswith("mt_final_state") or k.startswith("mt_prepare")) +
                                    3 * per_launch(lambda k: k.startswith("mt_combine_radix") or k.startswith("mt_expand")),
