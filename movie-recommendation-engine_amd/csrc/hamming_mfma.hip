@@ -507,9 +507,16 @@ template <int KS>
 int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t *bl, int64_t nq) {
     const size_t tiles_lds = (size_t)NBUF * IT * KS * 1024;
     const size_t lds = tiles_lds + (size_t)WAVES * CAP * 64 * sizeof(uint32_t);
-    static const bool lds_ok = allow_lds(hamming_mfma_kernel<KS, 0, 16>, 160 * 1024) &&
-                               allow_lds(hamming_mfma_kernel<KS, 0, 32>, 160 * 1024) &&
-                               allow_lds(hamming_mfma_kernel<KS, 1, 16>, 160 * 1024);
+    // once per (kernel, device): one process may drive several GPUs
+    static bool lds_done[64] = {};
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PS_ELAUNCH;
+    bool lds_ok = lds_done[devid];
+    if (!lds_ok) {
+        lds_ok = allow_lds(hamming_mfma_kernel<KS, 0, 16>, 160 * 1024) && allow_lds(hamming_mfma_kernel<KS, 0, 32>, 160 * 1024) &&
+                 allow_lds(hamming_mfma_kernel<KS, 1, 16>, 160 * 1024);
+        lds_done[devid] = lds_ok;
+    }
     if (!lds_ok) return PS_ELAUNCH;
     a.nqb = p.nqb;
     // bound
