@@ -128,3 +128,30 @@ def test_mfma_scan_full_catalogue_equals_popcount(nbits, d, k):
     assert bool((dm[:, 1:] >= dm[:, :-1]).all())
     tie = dm[:, 1:] == dm[:, :-1]
     assert bool((im[:, 1:][tie] > im[:, :-1][tie]).all())
+
+
+def test_mfma_scan_random_shapes_equal_popcount():
+    """seeded shape fuzz: the MFMA path and the popcount kernel must agree bit for bit on every served shape -- query counts
+    around the 32 / 256 tile boundaries, tables around the 32 / 64-item tile and slice boundaries, every k up to 32, all
+    code sizes, heavy ties (few distinct codes) and id offsets"""
+    from pinsage_hip import dense
+    rs = np.random.RandomState(2024)
+    shapes = [(64, 4096, 8, 1), (65, 4097, 64, 32), (255, 4159, 32, 16), (257, 8191, 16, 17), (1000, 12345, 64, 11)]
+    for _ in range(9):
+        shapes.append((int(rs.randint(64, 1500)), int(rs.randint(4096, 30000)), int(rs.choice([8, 16, 32, 64])),
+                       int(rs.randint(1, 33))))
+    for nq, N, cs, k in shapes:
+        few = rs.rand() < 0.3
+        if few:                                                  # ~200 distinct codes: long runs of equal distances
+            base = rs.randint(0, 256, size=(200, cs)).astype(np.uint8)
+            codes = base[rs.randint(0, 200, size=N)]
+        else:
+            codes = rs.randint(0, 256, size=(N, cs)).astype(np.uint8)
+        q = codes[rs.randint(0, N, size=nq)].copy()
+        q[::3] ^= rs.randint(0, 256, size=q[::3].shape).astype(np.uint8) & 1
+        ct, qt = torch.from_numpy(codes).cuda(), torch.from_numpy(q).cuda()
+        off = int(rs.randint(0, 2 ** 33))
+        assert dense.hamming_mfma_supported(nq, N, cs, k)
+        dm, im = dense.hamming_topk(qt, ct, k, id_offset=off, planes=dense.lsh_expand(ct))
+        dv, iv = dense.hamming_topk(qt, ct, k, id_offset=off, use_mfma=False)
+        assert torch.equal(dm, dv) and torch.equal(im, iv), (nq, N, cs, k, few)
