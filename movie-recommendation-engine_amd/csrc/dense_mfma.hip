@@ -282,6 +282,209 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// gemm_dma_kernel: the same arithmetic (v_mfma_f32_32x32x2_f32, k ascending, one accumulator per output: bit-identical
+// to the fmaf chain) with both operands brought into LDS by global_load_lds_dwordx4 -- no registers and no ds_write for
+// staging, a 3-deep ring, ONE barrier per 32-deep K step (gemm_f32_kernel: two barriers and a register -> LDS write pass
+// per step, the MFMA pipe 57 % busy).
+// LDS image of a stage: per 64-row block and 4-k slot kk one 1 KiB piece [64 rows][4 floats] -- lane = row, source =
+// 16 contiguous bytes of that row: lane-linear for the DMA and conflict-free for the fragment reads.  A lane (row i,
+// k half h) reads the whole 16-byte slot of its row and picks component 2 m + h for the m-th MFMA of the slot
+// (v_cndmask on the lane half), which keeps the contraction order k = 0, 1, 2, ... .
+// Block = 4 waves = 64 x 256 outputs (1 x 4 waves of 64 x 64), two 40 KiB stages: two blocks per CU, so one block's
+// prologue / epilogue overlaps the other's MFMAs (an 8-wave 128 x 256 block with three stages, one per CU, measured
+// 80 TFLOP/s against gemm_f32_kernel's 87).
+// The DMA is issued from inline asm with counted vmcnt (see csrc/hamming_mfma.hip for why).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void gemm_lds_dma16(const void *gptr, uint32_t lds_byte_offset) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte_offset) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+constexpr int DMA_BM = 64, DMA_BN = 256, DMA_BK = 32, DMA_STAGES = 2, DMA_WAVES = 4;
+constexpr int DMA_STAGE_BYTES = (DMA_BM + DMA_BN) * DMA_BK * 4;          // 40 KiB: two stages = 80 KiB, two blocks per CU
+constexpr int DMA_APIECES = DMA_BM / 64 * (DMA_BK / 4);                  // 8 one-KiB pieces of x per stage
+constexpr int DMA_PIECES = (DMA_BM + DMA_BN) / 64 * (DMA_BK / 4);        // 40 pieces per stage
+constexpr int DMA_PPW = DMA_PIECES / DMA_WAVES;                          // 10 per wave
+
+template <int EPI>
+__global__ __launch_bounds__(DMA_WAVES * 64, 2) void gemm_dma_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = 0, wn = wv;                              // 1 x 4 waves of 64 x 64 outputs
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * DMA_BM;
+    const int n0 = blockIdx.y * DMA_BN;
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(dsm);
+    const int nk1 = g.K / DMA_BK, nk2 = (g.x2 ? g.K2 : 0) / DMA_BK, nks = nk1 + nk2;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // piece p = wv + 4 q of a stage: p < 8: x rows lane, slot p;  else W rows ((p - 8) >> 3) * 64 + lane, slot p & 7.
+    // Per-lane source pointers of this wave's pieces, at k = 0 of the current operand pair (recomputed once, when the
+    // contraction moves from (x, W) to (x2, W2)); a K step only adds its byte offset.
+    const unsigned char *src[DMA_PPW];
+    auto sources = [&](bool second) {
+        const float *X = second ? g.x2 : g.x;
+        const float *Wp = second ? g.W2 : g.W;
+        const int K = second ? g.K2 : g.K;
+        const int ldw = second ? g.ldw2 : g.ldw;
+#pragma unroll
+        for (int q = 0; q < DMA_PPW; ++q) {
+            const int p = wv + DMA_WAVES * q;               // wave-uniform
+            const int kk = p & 7;
+            if (p < DMA_APIECES) {
+                int64_t row = m0 + lane;
+                row = row < g.M ? row : g.M - 1;            // rows past the end are clamped, their results never stored
+                src[q] = reinterpret_cast<const unsigned char *>(X + row * K + kk * 4);
+            } else {
+                int n = n0 + ((p - DMA_APIECES) >> 3) * 64 + lane;
+                n = n < g.N ? n : g.N - 1;
+                src[q] = reinterpret_cast<const unsigned char *>(Wp + (int64_t)n * ldw + kk * 4);
+            }
+        }
+    };
+    auto prefetch = [&](int ks, int buf) {
+        const int kbytes = (ks >= nk1 ? ks - nk1 : ks) * (DMA_BK * 4);
+#pragma unroll
+        for (int q = 0; q < DMA_PPW; ++q)
+            gemm_lds_dma16(src[q] + kbytes, lds_base + (uint32_t)(buf * DMA_STAGE_BYTES + (wv + DMA_WAVES * q) * 1024));
+    };
+
+    sources(nk1 == 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // nothing of the compiler's in flight (vmcnt(0), builtin form)
+    if (nks > 0) prefetch(0, 0);
+    int buf = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        // stage ks has landed (this wave's pieces; after the barrier everybody's) and everybody is done with the other
+        // buffer, which the next K step's DMA overwrites while this step is multiplied
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ks + 1 < nks) {
+            if (ks + 1 == nk1) sources(true);
+            prefetch(ks + 1, buf ^ 1);
+        }
+        const unsigned char *sA = dsm + buf * DMA_STAGE_BYTES + (wm * 8) * 1024 + li * 16;
+        const unsigned char *sB = dsm + buf * DMA_STAGE_BYTES + (DMA_APIECES + wn * 8) * 1024 + li * 16;
+        float4 fa[2][2], fb[2][2];                          // [slot parity][tile]
+        auto frags = [&](int kk, int s) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[s][a] = *reinterpret_cast<const float4 *>(sA + kk * 1024 + a * 512);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fb[s][b] = *reinterpret_cast<const float4 *>(sB + kk * 1024 + b * 512);
+        };
+        frags(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int kk = 0; kk < DMA_BK / 4; ++kk) {
+            const int s = kk & 1;
+            if (kk + 1 < DMA_BK / 4) {
+                frags(kk + 1, s ^ 1);                        // next slot's fragments before this slot's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                float av[2], bv[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) av[a] = m == 0 ? (lh ? fa[s][a].y : fa[s][a].x) : (lh ? fa[s][a].w : fa[s][a].z);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bv[b] = m == 0 ? (lh ? fb[s][b].y : fb[s][b].x) : (lh ? fb[s][b].w : fb[s][b].z);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+
+    // ------------------------------ epilogue (as gemm_f32_kernel) ------------------------------------------------
+    // C layout (32x32 tile): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (EPI == 1) {
+        uint32_t *codes32 = reinterpret_cast<uint32_t *>(g.codes);
+        const int words = g.cs >> 2;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int colbase = n0 + (wn * 2 + b) * 32;
+                const bool col_ok = colbase + li < g.N;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t mask = __ballot(col_ok && acc[a][b][r] >= 0.f);   // bit = (xt >= 0)
+                    const int64_t row = m0 + (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (li == 0 && row < g.M && colbase < g.N)
+                        codes32[row * words + (colbase >> 5)] = lh ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+                }
+            }
+        return;
+    }
+    const bool relu = g.flags & PS_RELU, l2 = g.flags & PS_L2NORM;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = n0 + (wn * 2 + b) * 32 + li;
+        const float bias = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[a][b][r] + bias;
+                if (relu) v = v > 0.f ? v : 0.f;
+                if (col >= g.N) v = 0.f;
+                acc[a][b][r] = v;
+            }
+    }
+    if (l2) {   // F.normalize(p=2, dim=1, eps=1e-12): the block holds whole rows (N <= 256); partial sums of the 4 column waves via LDS
+        float *sRed = reinterpret_cast<float *>(dsm);         // the ring is drained: every wave passed the last barrier ...
+        __syncthreads();                                      // ... and finished its fragment reads
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float ss = 0.f;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) ss = fmaf(acc[a][b][r], acc[a][b][r], ss);
+                ss = half_sum32(ss);
+                const int rowl = (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (li == 16) sRed[rowl * 4 + wn] = ss;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowl = (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float ss = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) ss += sRed[rowl * 4 + w];
+                float nrm = sqrtf(ss);
+                nrm = nrm > 1e-12f ? nrm : 1e-12f;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b][r] = acc[a][b][r] / nrm;
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row >= g.M) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int col = n0 + (wn * 2 + b) * 32 + li;
+                if (col < g.N) g.y[row * g.N + col] = acc[a][b][r];
+            }
+        }
+}
+
 __global__ void l2norm_rows_kernel(float *y, int64_t M, int N) {   // N > 256 only
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -333,6 +536,25 @@ template <int EPI>
 int launch_gemm(const GemmArgs &g, hipStream_t st) {
     const bool fast = aligned_operand(g.x, g.K, g.K) && aligned_operand(g.W, g.K, g.ldw) &&
                       (g.x2 == nullptr || (aligned_operand(g.x2, g.K2, g.K2) && aligned_operand(g.W2, g.K2, g.ldw2)));
+    // LDS-DMA kernel (opt-in, PS_GEMM_DMA=1: measured SLOWER than gemm_f32_kernel on MI355X, 82 vs 87.5 TFLOP/s for the
+    // layer GEMMs and 85 vs 94 for the LSH projection -- one barrier per K step and no staging registers do not pay for
+    // the doubled fragment reads, the lane-half selects and the 16-bytes-per-row DMA pieces; kept because it is tested
+    // bit-identical and documents the experiment): aligned operands, whole 256-column tiles, many rows
+    const bool use_dma = getenv("PS_GEMM_DMA") != nullptr;
+    if (fast && use_dma && g.N % DMA_BN == 0 && g.M >= 64 * 384) {
+        static bool attr_done[64] = {};
+        int devid = 0;
+        if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PS_ELAUNCH;
+        if (!attr_done[devid]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dma_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    DMA_STAGES * DMA_STAGE_BYTES) != hipSuccess) return PS_ELAUNCH;
+            attr_done[devid] = true;
+        }
+        dim3 grid((unsigned)ps_cdiv(g.M, DMA_BM), (unsigned)(g.N / DMA_BN));
+        hipLaunchKernelGGL((gemm_dma_kernel<EPI>), grid, dim3(DMA_WAVES * 64), DMA_STAGES * DMA_STAGE_BYTES, st, g);
+        PS_CHECK_LAUNCH();
+        return PS_OK;
+    }
     return fast ? launch_gemm_v<EPI, true>(g, st) : launch_gemm_v<EPI, false>(g, st);
 }
 

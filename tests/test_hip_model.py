@@ -509,3 +509,32 @@ def test_pinsage_pooled_forward_grad_reaches_input_with_frozen_params(golden):
     with torch.no_grad():
         e2 = m(x, sampled_neighbors=[nb0, nb1], importance_weights=[wt0, wt1])      # fused HIP path, same values
     np.testing.assert_allclose(e2.cpu().numpy(), e.detach().cpu().numpy(), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("M,K,N,K2,relu,l2", [(30000, 128, 256, 0, True, False), (40001, 256, 256, 256, True, True),
+                                              (59047, 256, 256, 0, False, True), (24576, 64, 512, 32, False, False)])
+def test_dma_gemm_is_bit_identical_to_the_register_staged_gemm(M, K, N, K2, relu, l2):
+    """gemm_dma_kernel (operands through LDS-DMA, one barrier per K step; opt-in with PS_GEMM_DMA=1 because it measured
+    slower) vs gemm_f32_kernel.  Same MFMA, same k order, same epilogue: outputs must be BIT-identical (the latter is held
+    to the fmaf-chain oracle by test_linear_vs_oracle), for ps_linear and for the LSH sign pack."""
+    import os
+    from pinsage_hip import dense
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    x2 = torch.randn(M, K2, generator=g).cuda() if K2 else None
+    W2 = (torch.randn(N, K2, generator=g) / K2 ** 0.5).cuda() if K2 else None
+    if N <= 256:
+        y_reg = dense.linear(x, W, b, x2=x2, W2=W2, relu=relu, l2norm=l2)
+    c_reg = dense.lsh_encode(x, W)
+    os.environ["PS_GEMM_DMA"] = "1"
+    try:
+        if N <= 256:
+            y_dma = dense.linear(x, W, b, x2=x2, W2=W2, relu=relu, l2norm=l2)
+        c_dma = dense.lsh_encode(x, W)
+    finally:
+        del os.environ["PS_GEMM_DMA"]
+    if N <= 256:
+        assert torch.equal(y_dma, y_reg)
+    assert torch.equal(c_dma, c_reg)
