@@ -1,10 +1,16 @@
 """Graph ingest from MovieLens-style rating rows: the edge_index / edge_weights layout of the
-reference's `MovieLensDataset._create_mappings` + `build_graph` (data/dataset.py:77-123), vectorised.
+reference's `MovieLensDataset._create_mappings` + `build_graph` (data/dataset.py:77-123), and the on-disk outputs of
+`inference.save_embeddings` (inference.py:146-170).
 
-The reference maps ids to indices in FIRST-APPEARANCE order (`Series.unique()` + enumerate, :80-86) and then
-looks every row up in a python dict (25 M dict lookups per column on ML-25M).  `pandas.factorize` yields exactly
-that numbering in one pass."""
+The reference maps ids to indices in FIRST-APPEARANCE order (`Series.unique()` + enumerate, :80-86) and then looks every
+row up in a python dict (25 M dict lookups per column on ML-25M: minutes).  Two equivalents:
+  build_graph_from_ratings          host: `pandas.factorize` yields exactly that numbering in one pass
+  build_graph_from_ratings_device   device: sort-unique + scatter-min of the row numbers gives every id its first row;
+                                    ranking the ids by that row is the first-appearance numbering.  The rating rows never
+                                    leave HBM and the result feeds DeviceGraph directly (ML-25M: ~25 ms instead of ~2 s)."""
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import pandas as pd
@@ -25,7 +31,43 @@ def build_graph_from_ratings(user_ids, movie_ids, ratings):
     return edge_index, edge_weights, movie_uniques, user_uniques
 
 
+def _first_appearance_index(ids):
+    """ids int64[R] (any device) -> (index of every row's id in first-appearance order int64[R], ids by index)."""
+    vals, inv = torch.unique(ids, sorted=True, return_inverse=True)
+    rows = torch.arange(ids.numel(), device=ids.device)
+    first = torch.full((vals.numel(),), ids.numel(), dtype=torch.int64, device=ids.device)
+    first.scatter_reduce_(0, inv, rows, reduce="amin")                 # first row of every distinct id
+    order = torch.argsort(first)                                       # distinct firsts: the order is unambiguous
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(order.numel(), device=ids.device)
+    return rank[inv], vals[order]
+
+
+def build_graph_from_ratings_device(user_ids, movie_ids, ratings, device="cuda"):
+    """The same (edge_index, edge_weights, movie_ids_by_index, user_ids_by_index), computed and left on `device`."""
+    dev = torch.device(device)
+    u_ids = torch.as_tensor(np.asarray(user_ids) if not isinstance(user_ids, torch.Tensor) else user_ids).to(dev, torch.int64)
+    m_ids = torch.as_tensor(np.asarray(movie_ids) if not isinstance(movie_ids, torch.Tensor) else movie_ids).to(dev, torch.int64)
+    m, movie_uniques = _first_appearance_index(m_ids)
+    u, user_uniques = _first_appearance_index(u_ids)
+    u = u + movie_uniques.numel()
+    edge_index = torch.stack([torch.cat([u, m]), torch.cat([m, u])], dim=0)
+    r = torch.as_tensor(np.asarray(ratings) if not isinstance(ratings, torch.Tensor) else ratings).to(dev, torch.float32)
+    return edge_index, torch.cat([r, r]), movie_uniques, user_uniques
+
+
 def build_graph_from_csv(ratings_csv):
     """ratings.csv with columns userId, movieId, rating (data/dataset.py:46-58)."""
     df = pd.read_csv(ratings_csv, usecols=["userId", "movieId", "rating"])
     return build_graph_from_ratings(df["userId"].values, df["movieId"].values, df["rating"].values)
+
+
+def save_embeddings(embeddings, output_dir, movie_ids_by_index):
+    """inference.py:146-170: `movie_embeddings.pt` (torch.save of the tensor as given) and `movie_mapping.csv`
+    (columns movieId,index in index order) under output_dir.  `movie_ids_by_index` is what the builders above return
+    (the reference passes the dataset and reads its movie_id_to_idx dict, whose order is the index order)."""
+    os.makedirs(output_dir, exist_ok=True)
+    torch.save(embeddings, os.path.join(output_dir, "movie_embeddings.pt"))
+    ids = movie_ids_by_index.cpu().numpy() if isinstance(movie_ids_by_index, torch.Tensor) else np.asarray(movie_ids_by_index)
+    pd.DataFrame({"movieId": ids, "index": np.arange(len(ids))}).to_csv(os.path.join(output_dir, "movie_mapping.csv"), index=False)
+    print(f"Saved embeddings and mapping to {output_dir}")

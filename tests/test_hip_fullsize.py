@@ -258,3 +258,22 @@ def test_whole_step_is_hipgraph_capturable(big):
             graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(e1, e0) and torch.equal(d1, d0) and torch.equal(i1, i0)
+
+
+def test_device_ingest_full_size_equals_host_factorize():
+    """SURVEY 8f-3 at ML-25M size: 25 M rating rows -> edge_index on the device (sort-unique + scatter-min first rows)
+    equals the host pandas.factorize path (itself pinned to the reference's build_graph by golden G8), and DeviceGraph
+    accepts the result."""
+    from pinsage_hip.graph import DeviceGraph
+    from pinsage_hip.ingest import build_graph_from_ratings, build_graph_from_ratings_device
+    g = torch.Generator().manual_seed(3)
+    R = 25_000_095
+    users = torch.randint(1, 162_542, (R,), generator=g) * 7 + 3            # sparse raw ids, like userId / movieId
+    movies = torch.randint(1, 59_048, (R,), generator=g) * 13 + 1
+    ratings = torch.randint(1, 11, (R,), generator=g).float() * 0.5
+    ei_d, ew_d, mu_d, uu_d = build_graph_from_ratings_device(users, movies, ratings)
+    ei_h, ew_h, mu_h, uu_h = build_graph_from_ratings(users.numpy(), movies.numpy(), ratings.numpy())
+    assert torch.equal(ei_d.cpu(), ei_h) and torch.equal(ew_d.cpu(), ew_h)
+    assert np.array_equal(mu_d.cpu().numpy(), np.asarray(mu_h)) and np.array_equal(uu_d.cpu().numpy(), np.asarray(uu_h))
+    dg = DeviceGraph(ei_d, ew_d)
+    assert dg.E == 2 * R and dg.V == len(mu_h) + len(uu_h) and not dg.has_reachable_sink

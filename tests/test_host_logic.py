@@ -222,6 +222,22 @@ def test_ingest_matches_reference_build_graph(golden2):
     assert np.array_equal(np.asarray(users), g["g8_user_ids_by_index"])
 
 
+def test_device_style_ingest_and_saved_outputs_match_the_reference(golden2, tmp_path, capsys):
+    """G8 through the torch formulation that runs on the GPU (here on CPU tensors: same code), and G12: the files
+    `inference.save_embeddings` (inference.py:146-170) writes -- movie_mapping.csv byte for byte, movie_embeddings.pt loads
+    back to the same tensor."""
+    from pinsage_hip.ingest import build_graph_from_ratings_device, save_embeddings
+    g = golden2
+    ei, ew, movies, users = build_graph_from_ratings_device(g["g8_userId"], g["g8_movieId"], g["g8_rating"], device="cpu")
+    assert np.array_equal(ei.numpy(), g["g8_edge_index"]) and np.array_equal(ew.numpy(), g["g8_edge_weights"])
+    assert np.array_equal(movies.numpy(), g["g8_movie_ids_by_index"]) and np.array_equal(users.numpy(), g["g8_user_ids_by_index"])
+    out = tmp_path / "out"
+    save_embeddings(torch.from_numpy(g["g12_embeddings"]), str(out), movies)
+    assert (out / "movie_mapping.csv").read_text() == str(g["g12_mapping_csv"])
+    assert np.array_equal(torch.load(out / "movie_embeddings.pt", weights_only=True).numpy(), g["g12_loaded"])
+    assert f"Saved embeddings and mapping to {out}" in capsys.readouterr().out
+
+
 def test_training_recipe_reproduces_reference_losses(golden2):
     """G10: the reference's `train.train` (train.py:8-124) drove the reference's PinSage for 3 epochs (MLP branch, Adam,
     CPU); the same recipe on the drop-in PinSage -- same initial parameters, same np.random stream -- must produce the
