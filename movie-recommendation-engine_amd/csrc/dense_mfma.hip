@@ -22,9 +22,39 @@
 // k-group g+1 are requested before the 16 MFMAs of group g (order pinned with sched_group_barrier).
 #include "ps_common.h"
 
+#ifndef PS_GEMM_DEBUG
+#define PS_GEMM_DEBUG 0    // knock-out experiments (tools/gemm_knockout.sh): 1 no global fetch after the first K step, 2 no LDS
+#endif                     // staging after it, 4 no barriers in the K loop, 8 no epilogue math, 16 fragments read once, 32 no stores
+
+#ifndef PS_GEMM_SPREAD
+#define PS_GEMM_SPREAD 1
+#endif
+#ifndef PS_GEMM_W2
+#define PS_GEMM_W2 0       // 1: permuting stash by ds_write2_b32 from inline asm (no v_mov): measured equal, its 8-byte writes conflict
+#endif
+#ifndef PS_GEMM_PRIO
+#define PS_GEMM_PRIO 0
+#endif
+#ifndef PS_GEMM_STAGGER
+#define PS_GEMM_STAGGER 0
+#endif
+
+#if PS_GEMM_DEBUG & 64      // timeline experiment (tools/gemm_trace.py): per wave HW_ID, XCC_ID and s_memtime stamps
+__device__ unsigned long long ps_gemm_trace_buf[4096 * 4 * 48];
+#define PS_TRACE(slot) do { if (lane == 0 && blockIdx.x < 4096 && (slot) < 48) \
+    ps_gemm_trace_buf[((size_t)blockIdx.x * 4 + (wv & 3)) * 48 + (slot)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int ps_debug_gemm_trace(unsigned long long *host, int clear) {
+    if (clear) { static unsigned long long z[4096 * 4 * 48]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(ps_gemm_trace_buf), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ps_gemm_trace_buf), sizeof(unsigned long long) * 4096 * 4 * 48);
+}
+#else
+#define PS_TRACE(slot) do {} while (0)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 struct GemmArgs {
@@ -47,31 +77,98 @@ __device__ __forceinline__ void load8(const float *base, bool row_ok, int k, int
     }
 }
 
-// Sum over the 32 lanes of each wave half, valid in lanes 16..31 / 48..63, with DPP only (the LDS crossbar that
-// __shfl_xor goes through is shared by the CU's waves: 160 shuffles per wave cost ~17 us per launch).
-#define PS_DPP_ADD(v, ctrl, rows) \
+// Sum over the 32 lanes of each wave half, valid in lanes 16..31 / 48..63, with DPP only (gemm_dma_kernel)
+#define PS_DPP_ACC(v, ctrl, rows) \
     (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rows), 0xf, true))
 __device__ __forceinline__ float half_sum32(float v) {
-    PS_DPP_ADD(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]: lane ^ 1
-    PS_DPP_ADD(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]: lane ^ 2
-    PS_DPP_ADD(v, 0x141, 0xf);   // row_half_mirror: the other quad of the 8
-    PS_DPP_ADD(v, 0x140, 0xf);   // row_mirror: the other 8 of the 16
-    PS_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15 -> rows 1 and 3 add the row before them
+    PS_DPP_ACC(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]: lane ^ 1
+    PS_DPP_ACC(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]: lane ^ 2
+    PS_DPP_ACC(v, 0x141, 0xf);   // row_half_mirror: the other quad of the 8
+    PS_DPP_ACC(v, 0x140, 0xf);   // row_mirror: the other 8 of the 16
+    PS_DPP_ACC(v, 0x142, 0xa);   // row_bcast:15 -> rows 1 and 3 add the row before them
     return v;
 }
+#undef PS_DPP_ACC
+
+// Row sums of the fused L2 norm.  Every lane holds NV partial sums (one per row of its wave tile: v[idx], idx = 16 a + r)
+// over ITS column; wanted: the sums over the 32 columns of the lane's wave half.  Reducing every value over 32 lanes takes
+// 5 NV DPP adds; a transposing butterfly halves the number of live values at every level instead (lane L keeps the values
+// whose idx bit equals a predicate of L and adds its partner's copy of the same values): 3 (NV/2 + NV/4 + ...) operations,
+// and every lane ends up with the complete sum of ONE idx (bits = its predicates).  Partners: quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror (gfx9 DPP has no xor 4 / xor 8), v_permlane16_swap for the two rows of the half; a mirror complements the lower
+// lane bits, so the predicates are b0^b2, b1^b2, b2^b3, b3, b4 -- each invariant under every LATER pairing, which keeps a
+// lane and its partner on the same set of rows.
+#define PS_DPP_ADD(v, ctrl) \
+    ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true)))
+template <int NV>
+__device__ __forceinline__ float transpose_sum32(float (&v)[NV], int lane) {
+    static_assert(NV == 16 || NV == 32, "one or two 32-row tiles per wave");
+    const bool p1 = ((lane ^ (lane >> 2)) & 1) != 0, p2 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0;
+    const bool p3 = (((lane >> 2) ^ (lane >> 3)) & 1) != 0, p4 = ((lane >> 3) & 1) != 0;
+#pragma unroll
+    for (int j = 0; j < NV / 2; ++j) {      // idx bit 0 <- p1
+        const float lo = PS_DPP_ADD(v[2 * j], 0xB1), hi = PS_DPP_ADD(v[2 * j + 1], 0xB1);      // quad_perm [1,0,3,2]
+        v[j] = p1 ? hi : lo;
+    }
+#pragma unroll
+    for (int j = 0; j < NV / 4; ++j) {      // idx bit 1 <- p2
+        const float lo = PS_DPP_ADD(v[2 * j], 0x4E), hi = PS_DPP_ADD(v[2 * j + 1], 0x4E);      // quad_perm [2,3,0,1]
+        v[j] = p2 ? hi : lo;
+    }
+#pragma unroll
+    for (int j = 0; j < NV / 8; ++j) {      // idx bit 2 <- p3
+        const float lo = PS_DPP_ADD(v[2 * j], 0x141), hi = PS_DPP_ADD(v[2 * j + 1], 0x141);    // row_half_mirror
+        v[j] = p3 ? hi : lo;
+    }
+#pragma unroll
+    for (int j = 0; j < NV / 16; ++j) {     // idx bit 3 <- p4
+        const float lo = PS_DPP_ADD(v[2 * j], 0x140), hi = PS_DPP_ADD(v[2 * j + 1], 0x140);    // row_mirror
+        v[j] = p4 ? hi : lo;
+    }
+    // the two 16-lane rows of the half: v_permlane16_swap(x, y) exchanges x's odd rows with y's even rows
+    const float x = v[0], y = NV == 32 ? v[1] : v[0];
+    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+    const unsigned s0 = sw[0], s1 = sw[1];   // ([x.row0, y.row0, ..], [x.row1, y.row1, ..]): the sum is x's total in even rows, y's in odd
+    return __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);            // idx bit 4 <- b4 (NV == 32)
+}
 #undef PS_DPP_ADD
+
+// One (row, 8-k group) item, registers lo = k 0..3, hi = k 4..7, into its LDS image [lane half h][4] = k 2 t + h.
+// ds_write2_b32 takes its two dwords from two unrelated registers, so the permutation costs no register moves (40 v_mov
+// per thread and K step between the two barriers, where nothing hides them: knock-out 15 of 166 us).
+template <bool PIN>
+__device__ __forceinline__ void stash_item(float *d, f32x4 lo, f32x4 hi) {
+#if PS_GEMM_W2
+    const uint32_t a = (uint32_t)(uintptr_t)d;       // LDS byte address
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\t"
+                 "ds_write2_b32 %0, %3, %4 offset0:2 offset1:3\n\t"
+                 "ds_write2_b32 %0, %5, %6 offset0:4 offset1:5\n\t"
+                 "ds_write2_b32 %0, %7, %8 offset0:6 offset1:7"
+                 :: "v"(a), "v"(lo[0]), "v"(lo[2]), "v"(hi[0]), "v"(hi[2]), "v"(lo[1]), "v"(lo[3]), "v"(hi[1]), "v"(hi[3]) : "memory");
+#else
+    if (PIN) asm volatile("" : "+v"(lo), "+v"(hi));  // pins the moves behind the barrier (else: vmcnt waits among the MFMAs)
+    *reinterpret_cast<f32x4 *>(d) = f32x4{lo[0], lo[2], hi[0], hi[2]};
+    *reinterpret_cast<f32x4 *>(d + 4) = f32x4{lo[1], lo[3], hi[1], hi[3]};
+#endif
+}
 
 // FAST: every operand is 16-B aligned with K % BK == 0 -> unconditional float4 loads (rows past the end are
 // clamped to the last valid row; their results are never stored), so nothing branches or waits inside the
 // fetch and the loads stay in flight under the MFMAs.  The general variant predicates every element.
 template <int WM, int WN, int TM, int TN, int BK, int EPI, bool FAST>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
+#ifndef PS_GEMM_OCC
+#define PS_GEMM_OCC 2      // two blocks per CU (<= 256 VGPR + AGPR): one block's barriers and epilogue under the other's MFMAs
+#endif
+__global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+    // global loads of the next K step spread over the MFMAs (below): pays for the 2 x 2-tile waves (10 loads per 64 MFMAs);
+    // the 1 x 2-tile blocks measured 3 % slower with it (LSH projection 0.151 -> 0.155 ms)
+    constexpr bool SPREAD = FAST && PS_GEMM_SPREAD && TM * TN >= 4;
     constexpr int GRP = BK / 8;                        // 8-k groups per row
     constexpr int LDS_STRIDE = BK + 4;                 // floats; 144 B (BK 32) / 80 B (BK 16): b128 reads conflict free
     constexpr int A_ITEMS = (BM * GRP + NT - 1) / NT, B_ITEMS = (BN * GRP + NT - 1) / NT;   // (row, group) items per thread
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_STRIDE + BM * WN];
-    float *sA = smem, *sB = smem + BM * LDS_STRIDE, *sRed = smem + (BM + BN) * LDS_STRIDE;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_STRIDE + BM * WN + BM * 4];
+    float *sA = smem, *sB = smem + BM * LDS_STRIDE, *sRed = smem + (BM + BN) * LDS_STRIDE, *sNrm = sRed + BM * WN;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
@@ -79,6 +176,43 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
     const int n0 = blockIdx.y * BN;
     const int li = lane & 31, lh = lane >> 5;
 
+#if PS_GEMM_PRIO == 1
+    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2);
+#elif PS_GEMM_PRIO == 2
+    {   // the wave slot (HW_ID.wave_id) of the block's first wave: the two blocks that share a CU sit in different slots
+        if (tid == 0) reinterpret_cast<volatile int *>(sRed)[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1;
+        __syncthreads();
+        const int odd = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile int *>(sRed)[0]);
+        __syncthreads();
+        if (odd) __builtin_amdgcn_s_setprio(2);
+    }
+#endif
+#if PS_GEMM_DEBUG & 64
+    if (lane == 0 && blockIdx.x < 4096) {
+        ps_gemm_trace_buf[((size_t)blockIdx.x * 4 + (wv & 3)) * 48 + 46] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);    // HW_ID
+        ps_gemm_trace_buf[((size_t)blockIdx.x * 4 + (wv & 3)) * 48 + 47] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);   // XCC_ID
+    }
+    int trace_step = 0;
+#endif
+#if PS_GEMM_STAGGER
+    // the blocks of the first round all start together, run the same program at the same speed and therefore reach their
+    // epilogues together: the whole chip stops multiplying and writes 33 MB at once (tools/gemm_trace.py: the epilogue takes
+    // 22 % of a block's life, mostly store back-pressure).  Holding back the second block of every CU de-phases the two
+    // residents for the rest of the launch (their successors inherit the offset); the first block has the MFMA pipe to itself
+    // meanwhile, so nothing is lost.
+    if (blockIdx.x < 2 * 256 && gridDim.x > 2 * 256) {
+        const int slot = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 4)) & 1;
+        if (tid == 0) reinterpret_cast<volatile int *>(sRed)[0] = slot;
+        __syncthreads();
+        const int held = reinterpret_cast<volatile int *>(sRed)[0];
+        __syncthreads();
+        if (held) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__builtin_readcyclecounter() - t0 < (unsigned long long)PS_GEMM_STAGGER) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+#endif
+    PS_TRACE(0);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -96,7 +230,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
         const bool vecA = (K % 4 == 0) && (reinterpret_cast<size_t>(X) % 16 == 0);
         const bool vecB = (ldw % 4 == 0) && (reinterpret_cast<size_t>(Wp) % 16 == 0);
 
-        float ra[A_ITEMS][8], rb[B_ITEMS][8];
+        // staging registers: the two 16-byte halves of every (row, 8-k group) item, as loaded
+        f32x4 ra[A_ITEMS][2], rb[B_ITEMS][2];
         auto fetch = [&](int k0) {
 #pragma unroll
             for (int q = 0; q < A_ITEMS; ++q) {
@@ -105,93 +240,112 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
                 const int it = FAST ? (tid + NT * q) % (BM * GRP) : tid + NT * q, row = it / GRP, grp = it % GRP;
                 const int64_t m = m0 + row;
                 if (FAST) {
-                    {
-                        const float *src = X + (m < g.M ? m : g.M - 1) * K + k0 + grp * 8;
-                        const float4 a = *reinterpret_cast<const float4 *>(src);
-                        const float4 b = *reinterpret_cast<const float4 *>(src + 4);
-                        ra[q][0] = a.x; ra[q][1] = a.y; ra[q][2] = a.z; ra[q][3] = a.w;
-                        ra[q][4] = b.x; ra[q][5] = b.y; ra[q][6] = b.z; ra[q][7] = b.w;
-                    }
-                } else if (it < BM * GRP) load8(X + m * K, m < g.M, k0 + grp * 8, K, vecA, ra[q]);
+                    const float *src = X + (m < g.M ? m : g.M - 1) * K + k0 + grp * 8;
+                    ra[q][0] = *reinterpret_cast<const f32x4 *>(src);
+                    ra[q][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+                } else if (it < BM * GRP) {
+                    float v[8];
+                    load8(X + m * K, m < g.M, k0 + grp * 8, K, vecA, v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ra[q][0][j] = v[j]; ra[q][1][j] = v[4 + j]; }
+                }
             }
 #pragma unroll
             for (int q = 0; q < B_ITEMS; ++q) {
                 const int it = FAST ? (tid + NT * q) % (BN * GRP) : tid + NT * q, row = it / GRP, grp = it % GRP;
                 const int n = n0 + row;
                 if (FAST) {
-                    {
-                        const float *src = Wp + (int64_t)(n < g.N ? n : g.N - 1) * ldw + k0 + grp * 8;
-                        const float4 a = *reinterpret_cast<const float4 *>(src);
-                        const float4 b = *reinterpret_cast<const float4 *>(src + 4);
-                        rb[q][0] = a.x; rb[q][1] = a.y; rb[q][2] = a.z; rb[q][3] = a.w;
-                        rb[q][4] = b.x; rb[q][5] = b.y; rb[q][6] = b.z; rb[q][7] = b.w;
-                    }
-                } else if (it < BN * GRP) load8(Wp + (int64_t)n * ldw, n < g.N, k0 + grp * 8, K, vecB, rb[q]);
+                    const float *src = Wp + (int64_t)(n < g.N ? n : g.N - 1) * ldw + k0 + grp * 8;
+                    rb[q][0] = *reinterpret_cast<const f32x4 *>(src);
+                    rb[q][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+                } else if (it < BN * GRP) {
+                    float v[8];
+                    load8(Wp + (int64_t)n * ldw, n < g.N, k0 + grp * 8, K, vecB, v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { rb[q][0][j] = v[j]; rb[q][1][j] = v[4 + j]; }
+                }
             }
         };
+        // LDS image of an item: [lane half h][4] = k 2 t + h.  The empty asm pins the permuting register moves HERE, after
+        // the barrier: left to itself the compiler performs them right behind the loads, i.e. waits for global memory
+        // inside the MFMA stream of the previous step
         auto stash = [&]() {
 #pragma unroll
             for (int q = 0; q < A_ITEMS; ++q) {
                 const int it = FAST ? (tid + NT * q) % (BM * GRP) : tid + NT * q, row = it / GRP, grp = it % GRP;
                 if (!FAST && it >= BM * GRP) continue;
                 float *d = sA + row * LDS_STRIDE + grp * 8;
-                *reinterpret_cast<float4 *>(d) = make_float4(ra[q][0], ra[q][2], ra[q][4], ra[q][6]);
-                *reinterpret_cast<float4 *>(d + 4) = make_float4(ra[q][1], ra[q][3], ra[q][5], ra[q][7]);
+                stash_item<SPREAD>(d, ra[q][0], ra[q][1]);
             }
 #pragma unroll
             for (int q = 0; q < B_ITEMS; ++q) {
                 const int it = FAST ? (tid + NT * q) % (BN * GRP) : tid + NT * q, row = it / GRP, grp = it % GRP;
                 if (!FAST && it >= BN * GRP) continue;
                 float *d = sB + row * LDS_STRIDE + grp * 8;
-                *reinterpret_cast<float4 *>(d) = make_float4(rb[q][0], rb[q][2], rb[q][4], rb[q][6]);
-                *reinterpret_cast<float4 *>(d + 4) = make_float4(rb[q][1], rb[q][3], rb[q][5], rb[q][7]);
+                stash_item<SPREAD>(d, rb[q][0], rb[q][1]);
             }
         };
 
         fetch(0);
         for (int k0 = 0; k0 < K; k0 += BK) {
-            __syncthreads();           // previous step's fragment reads are done
-            stash();
-            __syncthreads();
-            if (k0 + BK < K) fetch(k0 + BK);
+#if PS_GEMM_DEBUG & 64
+            PS_TRACE(2 + 2 * trace_step);                                   // end of the step's MFMA stream (issue)
+#endif
+            if (!(PS_GEMM_DEBUG & 4) || k0 == 0) __syncthreads();           // previous step's fragment reads are done
+            if (!(PS_GEMM_DEBUG & 2) || k0 == 0) stash();
+            if (PS_GEMM_W2) __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the asm's LDS writes have landed
+            if (!(PS_GEMM_DEBUG & 4) || k0 == 0) __syncthreads();
+#if PS_GEMM_DEBUG & 64
+            PS_TRACE(3 + 2 * trace_step);                                   // image published: MFMA stream starts
+            ++trace_step;
+#endif
+            // FAST: unconditional (the last step re-reads its own slab: harmless) so that the loads, the fragment reads and
+            // the MFMAs of a step are ONE basic block and the issue order below applies to all of them
+            if (SPREAD && !(PS_GEMM_DEBUG & 1)) fetch(k0 + BK < K ? k0 + BK : k0);
+            else if (k0 + BK < K && !(PS_GEMM_DEBUG & 1)) fetch(k0 + BK);
             // fragments of group g+1 are requested BEFORE group g's MFMAs: the two waves of a SIMD run in lockstep
             // (same barriers, round-robin issue), so an LDS round trip taken between groups idles the MFMA pipe for
             // both of them -- measured 65 % pipe use without this prefetch
-            float4 fa[2][TM], fb[2][TN];
+            f32x4 fa[2][TM], fb[2][TN];
             auto frags = [&](int grp, int s) {
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
-                    fa[s][a] = *reinterpret_cast<const float4 *>(sA + ((wm * TM + a) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
+                    fa[s][a] = *reinterpret_cast<const f32x4 *>(sA + ((wm * TM + a) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    fb[s][b] = *reinterpret_cast<const float4 *>(sB + ((wn * TN + b) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
+                    fb[s][b] = *reinterpret_cast<const f32x4 *>(sB + ((wn * TN + b) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
             };
-            frags(0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);           // keep this order: DS reads ...
+            if (!(PS_GEMM_DEBUG & 16) || k0 == 0) frags(0, 0);
 #pragma unroll
             for (int grp = 0; grp < GRP; ++grp) {
-                const int s = grp & 1;
-                if (grp + 1 < GRP) {
-                    frags(grp + 1, s ^ 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // ... next group's DS reads first,
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);   // ... then this group's MFMAs
+                const int s = (PS_GEMM_DEBUG & 16) ? 0 : grp & 1;
+                if (grp + 1 < GRP && !(PS_GEMM_DEBUG & 16)) frags(grp + 1, s ^ 1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][a][t], fb[s][b][t], acc[a][b], 0, 0, 0);
+            }
+            // issue order of the step (one basic block): the fragments of group g+1 are requested BEFORE group g's MFMAs
+            // (the compiler otherwise sinks the reads behind them), and the global loads of the next K step are spread
+            // over the MFMAs, one after every TM*TN of them: issued in one burst after the barrier they kept all eight
+            // waves of the CU in the address path while the MFMA pipe idled (knock-out: 22 of 176 us)
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+            for (int grp = 0; grp < GRP; ++grp) {
+                if (grp + 1 < GRP) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) {
-                        const float av = t == 0 ? fa[s][a].x : t == 1 ? fa[s][a].y : t == 2 ? fa[s][a].z : fa[s][a].w;
-#pragma unroll
-                        for (int b = 0; b < TN; ++b) {
-                            const float bv = t == 0 ? fb[s][b].x : t == 1 ? fb[s][b].y : t == 2 ? fb[s][b].z : fb[s][b].w;
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
-                        }
-                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                    if (SPREAD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             }
         }
     }
 
+    PS_TRACE(40);
     // ------------------------------ epilogue -------------------------------------------------
     // C layout (32x32 tile): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (EPI == 1) {
@@ -211,10 +365,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
                         codes32[row * words + (colbase >> 5)] = lh ? (uint32_t)(mask >> 32) : (uint32_t)mask;
                 }
             }
+        PS_TRACE(41);
         return;
     }
 
-    const bool relu = g.flags & PS_RELU, l2 = g.flags & PS_L2NORM;
+    const bool relu = (g.flags & PS_RELU) && !(PS_GEMM_DEBUG & 8), l2 = (g.flags & PS_L2NORM) && !(PS_GEMM_DEBUG & 8);
+    if (PS_GEMM_DEBUG & 32) {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+        if (s == 12345.678f) g.y[0] = s;
+        PS_TRACE(41);
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int col = n0 + (wn * TN + b) * 32 + li;
@@ -229,33 +396,82 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
                 acc[a][b][r] = v;
             }
     }
+    PS_TRACE(42);
     if (l2) {   // F.normalize(p=2, dim=1, eps=1e-12): x / max(||x||, eps); the block holds whole rows
+        float ss[TM * 16];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float ss = 0.f;
+                float t = 0.f;
 #pragma unroll
-                for (int b = 0; b < TN; ++b) ss = fmaf(acc[a][b][r], acc[a][b][r], ss);
-                ss = half_sum32(ss);                                            // over the 32 columns of the half
-                const int rowl = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (li == 16) sRed[rowl * WN + wn] = ss;
+                for (int b = 0; b < TN; ++b) t = fmaf(acc[a][b][r], acc[a][b][r], t);
+                ss[a * 16 + r] = t;
             }
+        const float tot = transpose_sum32<TM * 16>(ss, lane);               // this wave's columns of ONE row per lane:
+        {                                                                   // idx bits = the butterfly's predicates
+            const int idx = ((lane ^ (lane >> 2)) & 1) | (((lane >> 1) ^ (lane >> 2)) & 1) << 1 | (((lane >> 2) ^ (lane >> 3)) & 1) << 2 |
+                            (lane & 8) | (TM == 2 ? lane & 16 : 0);
+            const int a = idx >> 4, r = idx & 15;
+            const int rowl = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (TM == 2 || li < 16) sRed[rowl * WN + wn] = tot;
+        }
+        PS_TRACE(43);
         __syncthreads();
+        // one thread per row: norm, its correctly rounded reciprocal, the fast path's guard (see below)
+        for (int row = tid; row < BM; row += NT) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) t += sRed[row * WN + w];
+            float nrm = sqrtf(t);
+            nrm = nrm > 1e-12f ? nrm : 1e-12f;
+            const bool tame = nrm >= 0x1p-40f && nrm <= 0x1p40f;
+            *reinterpret_cast<f32x4 *>(sNrm + row * 4) = f32x4{nrm, 1.0f / nrm, nrm * 0x1p-60f, tame ? 0.f : 1.f};
+        }
+        __syncthreads();
+        PS_TRACE(44);
+        // x / nrm, IEEE-exact, without 64 v_div sequences per lane (11 instructions each; the epilogue was 22 % of a block's
+        // life, tools/gemm_trace.py): with y = RN(1 / nrm), q0 = x y is within 1.5 ulp, q1 = q0 + (x - nrm q0) y is a faithful
+        // quotient and q2 = q1 + (x - nrm q1) y is the correctly rounded one (Markstein's theorem; the remainders are exact
+        // in an fma) -- as long as nothing underflows on the way: the row's norm in [2^-40, 2^40] and x = 0 or
+        // |x| >= 2^-60 nrm.  A wave that sees anything else divides the ordinary way (tools/ubench/div_check.hip counts
+        // mismatches of the fast path against a / b: none in 6.9e10 pairs, half of them next to rounding boundaries).
+        bool wild = false;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rowl = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float ss = 0.f;
+                const f32x4 nr = *reinterpret_cast<const f32x4 *>(sNrm + ((wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4);
+                wild |= nr[3] != 0.f;
 #pragma unroll
-                for (int w = 0; w < WN; ++w) ss += sRed[rowl * WN + w];
-                float nrm = sqrtf(ss);
-                nrm = nrm > 1e-12f ? nrm : 1e-12f;
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b][r] = acc[a][b][r] / nrm;
+                for (int b = 0; b < TN; ++b) wild |= acc[a][b][r] != 0.f && !(fabsf(acc[a][b][r]) >= nr[2]);
             }
+        if (__builtin_amdgcn_ballot_w64(wild) == 0) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 nr = *reinterpret_cast<const f32x4 *>(sNrm + ((wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4);
+                    const float nrm = nr[0], y = nr[1];
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const float x = acc[a][b][r];
+                        const float q0 = x * y, q1 = fmaf(fmaf(-nrm, q0, x), y, q0);
+                        acc[a][b][r] = fmaf(fmaf(-nrm, q1, x), y, q1);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float nrm = sNrm[((wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4];
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b][r] = acc[a][b][r] / nrm;
+                }
+        }
     }
+    PS_TRACE(45);
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);     // block-uniform: no per-element guards
     if (interior) {
 #pragma unroll
@@ -266,6 +482,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                 for (int b = 0; b < TN; ++b) dst[b * 32] = acc[a][b][r];
             }
+        PS_TRACE(41);
         return;
     }
 #pragma unroll
@@ -280,6 +497,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
                 if (col < g.N) g.y[row * g.N + col] = acc[a][b][r];
             }
         }
+    PS_TRACE(41);
 }
 
 // ------------------------------------------------------------------------------------------------------------
