@@ -727,7 +727,8 @@ int launch_gemm_v(const GemmArgs &g, hipStream_t st) {
         hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
     } else {
         if (!(g.flags & PS_L2NORM)) {
-            // no row reduction in the epilogue: 64 x 128 tiles (twice the resident waves) measured 2-7 % faster
+            // no row reduction in the epilogue: 64 x 128 tiles (twice the resident waves) measured 2-7 % faster (r02, with the
+            // spread loads in the 64 x 256 kernel: input projection equal, LSH projection still 7 % faster)
             dim3 grid((unsigned)ps_cdiv(g.M, 64), (unsigned)ps_cdiv(g.N, 128));
             hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
         } else if (g.M < 64 * 384) {
