@@ -433,7 +433,7 @@ __global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(Gem
         // x / nrm, IEEE-exact, without 64 v_div sequences per lane (11 instructions each; the epilogue was 22 % of a block's
         // life, tools/gemm_trace.py): with y = RN(1 / nrm), q0 = x y is within 1.5 ulp, q1 = q0 + (x - nrm q0) y is a faithful
         // quotient and q2 = q1 + (x - nrm q1) y is the correctly rounded one (Markstein's theorem; the remainders are exact
-        // in an fma) -- as long as nothing underflows on the way: the row's norm in [2^-40, 2^40] and x = 0 or
+        // in an fma) -- as long as nothing underflows on the way: the row's norm in [2^-40, 2^40] and x = +0 or
         // |x| >= 2^-60 nrm.  A wave that sees anything else divides the ordinary way (tools/ubench/div_check.hip counts
         // mismatches of the fast path against a / b: none in 6.9e10 pairs, half of them next to rounding boundaries).
         bool wild = false;
@@ -444,7 +444,8 @@ __global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(Gem
                 const f32x4 nr = *reinterpret_cast<const f32x4 *>(sNrm + ((wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4);
                 wild |= nr[3] != 0.f;
 #pragma unroll
-                for (int b = 0; b < TN; ++b) wild |= acc[a][b][r] != 0.f && !(fabsf(acc[a][b][r]) >= nr[2]);
+                for (int b = 0; b < TN; ++b)                      // -0 counts as nonzero: the corrections would return +0
+                    wild |= __float_as_uint(acc[a][b][r]) != 0u && !(fabsf(acc[a][b][r]) >= nr[2]);
             }
         if (__builtin_amdgcn_ballot_w64(wild) == 0) {
 #pragma unroll

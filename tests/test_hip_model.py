@@ -538,3 +538,40 @@ def test_dma_gemm_is_bit_identical_to_the_register_staged_gemm(M, K, N, K2, relu
     if N <= 256:
         assert torch.equal(y_dma, y_reg)
     assert torch.equal(c_dma, c_reg)
+
+
+@pytest.mark.parametrize("M,N", [(70, 256), (25000, 256), (90, 128), (50, 64)])
+def test_fused_norm_quotient_is_the_ieee_division(M, N):
+    """The fused row-normalise epilogue (csrc/dense_mfma.hip) divides by fma corrections of x * RN(1/norm) on its fast path
+    and by v_div when a wave sees a value outside that path's domain: both must be the IEEE quotient
+    x / max(||x||, 1e-12) of F.normalize (reference model/pinsage.py:240,249), bit for bit.  Rows have at most two
+    nonzeros in different lanes, so the norm itself is independent of the summation order (RN(RN(a^2) + RN(b^2))) and
+    numpy float32 restates it exactly; W = I makes the GEMM exact.  Covered: ordinary values, quotients next to 1, ratios
+    below 2^-60 (slow path), norms above 2^40 and below 2^-40 (slow path), the 1e-12 clamp, zero rows, subnormal
+    inputs, a negative zero input -- in all four tile shapes (N = 64 / 128, 256 with few / many rows)."""
+    from pinsage_hip import dense
+    rs = np.random.RandomState(M + N)
+    x = np.zeros((M, N), dtype=np.float32)
+    a = (rs.standard_normal(M) * np.exp2(rs.randint(-20, 20, size=M))).astype(np.float32)
+    b = (rs.standard_normal(M) * np.exp2(rs.randint(-20, 20, size=M))).astype(np.float32)
+    c0, c1 = rs.randint(0, 32, size=M), 32 + rs.randint(0, N - 32, size=M)      # different lanes (c1 != c0 mod 32 enforced below)
+    c1 = np.where(c1 % 32 == c0, c1 + 1 - 2 * (c1 % 32 == 31), c1)
+    x[np.arange(M), c0], x[np.arange(M), c1] = a, b
+    special = {1: (3.0, 4.0), 2: (1.0, 1e-30), 3: (1e25, 3e24), 4: (0.0, 0.0), 5: (1e-20, 0.0), 6: (1e-13, 2e-13),
+               7: (1e-42, 3e-41), 8: (-0.0, 5.0), 9: (np.float32(1.0) - np.float32(2.0 ** -24), 2.0 ** -13), 10: (2e-19, 1.0),
+               11: (1e-38, 1e-38), 12: (3e38, 0.0), 13: (-7.5, 1e-22)}
+    for r, (u, v) in special.items():
+        if r < M:
+            x[r] = 0
+            x[r, 0], x[r, 33] = u, v
+    eye = torch.eye(N, device="cuda")
+    y = dense.linear(torch.from_numpy(x).cuda(), eye, None, l2norm=True).cpu().numpy()
+    x = x + np.float32(0.0)                                      # the fma chain of the GEMM starts at +0: -0 comes out as +0
+    with np.errstate(over="ignore", under="ignore"):
+        sq = x * x                                               # RN(a^2) per element, float32
+        nrm = np.sqrt(sq.sum(axis=1, dtype=np.float32))          # <= 2 nonzeros: one rounding, order-free
+        want = x / np.maximum(nrm, np.float32(1e-12))[:, None]
+    want = want.astype(np.float32)
+    bad = np.argwhere(y.view(np.uint32) != want.view(np.uint32))
+    assert y.dtype == np.float32 and bad.size == 0, [(int(r), int(c), float(x[r, c]), float(nrm[r]), float(y[r, c]), float(want[r, c]))
+                                                      for r, c in bad[:8]]
