@@ -16,6 +16,10 @@
 // Without polynomials (or for short requests) a single workgroup generates the stream serially.
 #include "ps_common.h"
 
+#ifndef PS_MT_DEBUG
+#define PS_MT_DEBUG 0     // knock-outs (tools/mt_knockout.sh; wrong results): jump product 1 no nibble-stream build, 2 A operands
+#endif                    // loaded once, 4 no parity epilogue, 8 no MFMA; chunk generator 16 no stores, 32 no barrier
+
 namespace {
 
 constexpr int MT_N = 624, MT_M = 397;
@@ -50,6 +54,33 @@ __device__ __forceinline__ void next_block(const uint32_t *o, uint32_t *n, int t
         else if (t == 169) n[623] = b ^ twist(o[623], o[MT_M] ^ twist(o[0], o[1]));
     }
     __syncthreads();
+}
+
+// the same update with every new word also handed to emit(i, v) straight from the producing thread's registers: consumers
+// that copy each block to memory (sequence expansion, chunk generation) otherwise re-read the finished block from LDS
+// after the barrier -- a second LDS round trip in a serial chain of 34 / 210 blocks (chunks: 1500 -> 1100 cycles per block)
+template <typename Emit>
+__device__ __forceinline__ void next_block_emit(const uint32_t *o, uint32_t *n, int t, Emit emit) {
+    if (t < 227) {
+        // every operand is requested up front (ONE LDS round trip per block; thread 169's four extra words are broadcast reads
+        // for everybody, threads 170..226 re-read a valid pair they do not use)
+        const int t3 = t < 169 ? 454 + t : 622;
+        const uint32_t x0 = o[t], x1 = o[t + 1], xm = o[t + MT_M], y0 = o[227 + t], y1 = o[228 + t], z0 = o[t3], z1 = o[t3 + 1];
+        const uint32_t l623 = o[623], lm = o[MT_M], l0 = o[0], l1 = o[1];
+        const uint32_t a = xm ^ twist(x0, x1);
+        const uint32_t b = a ^ twist(y0, y1);
+        const uint32_t c = b ^ (t < 169 ? twist(z0, z1) : twist(l623, lm ^ twist(l0, l1)));
+        n[t] = a;
+        n[227 + t] = b;
+        emit(t, a);
+        emit(227 + t, b);
+        if (t <= 169) {
+            const int i3 = t < 169 ? 454 + t : 623;
+            n[i3] = c;
+            emit(i3, c);
+        }
+    }
+    if (!(PS_MT_DEBUG & 32)) __syncthreads();
 }
 
 // ---- serial path: one workgroup, raw (tempered) words written in place of the doubles ----------------------
@@ -107,29 +138,29 @@ constexpr int PW = MT_N / JP;                            // polynomial words per
 constexpr int SEQ_PAD = 34 * MT_N;                       // expanded sequence per source, whole blocks
 static_assert(SEQ_PAD >= DEG + MT_N && JP * PW == MT_N, "jump geometry");
 
-__device__ __forceinline__ uint32_t load_window_word(const uint32_t *parts, int t) {
+__device__ __forceinline__ uint32_t load_window_word(const uint32_t *parts, int nparts, int t) {
     uint32_t v = 0;
-#pragma unroll
-    for (int p = 0; p < JP; ++p) v ^= parts[p * MT_N + t];
+    for (int p = 0; p < nparts; ++p) v ^= parts[p * MT_N + t];
     return v;
 }
 
 // seq[b] = the 34 * 624 words that start with window b (sequential expansion, one workgroup per source)
-__global__ __launch_bounds__(256) void mt_expand_kernel(const uint32_t *src_parts, uint32_t *seq) {
+// (source window of block b = src + b * src_stride words, stored as nparts partial vectors: JP, or 1 for a plain window)
+__global__ __launch_bounds__(256) void mt_expand_kernel(const uint32_t *src, int nparts, int64_t src_stride, uint32_t *seq) {
     __shared__ uint32_t mt[2][MT_N];
     const int t = threadIdx.x;
     uint32_t *out = seq + (size_t)blockIdx.x * SEQ_PAD;
     for (int i = t; i < MT_N; i += 256) {
-        const uint32_t v = load_window_word(src_parts + (size_t)blockIdx.x * JP * MT_N, i);
+        const uint32_t v = load_window_word(src + (size_t)blockIdx.x * src_stride, nparts, i);
         mt[0][i] = v;
         out[i] = v;
     }
     __syncthreads();
     int cur = 0;
     for (int blk = 1; blk < 34; ++blk) {
-        next_block(mt[cur], mt[cur ^ 1], t);
+        uint32_t *dst = out + blk * MT_N;
+        next_block_emit(mt[cur], mt[cur ^ 1], t, [&](int i, uint32_t v) { dst[i] = v; });
         cur ^= 1;
-        for (int i = t; i < MT_N; i += 256) out[blk * MT_N + i] = mt[cur][i];
     }
 }
 
@@ -193,26 +224,212 @@ __global__ __launch_bounds__(192) void mt_combine_radix_kernel(const uint32_t *s
                  states + ((size_t)tgt * JP + part) * MT_N);
 }
 
+// ---- jump products on the matrix cores -----------------------------------------------------------------------------
+// A radix round applies up to 31 jump polynomials g_m to the same source window:
+//     out_m[j] = XOR_{i : g_m[i] = 1} seq[i + j],   j < 624
+// (seq = the source's expanded sequence).  Bit b of out_m[j] is the parity of  sum_i g_m[i] * plane_b[i + j]  with plane_b[p] =
+// bit b of seq[p]: per bit plane a (32 polynomials) x (19 937) x (624 lags) matrix product with a HANKEL right operand.
+// Both operands are 0 / 1, stored as fp4 (1.0 = 0x2) and contracted with v_mfma_scale_f32_32x32x64_f8f6f4 (block scales
+// 2^0): every partial sum is an integer below 2^24, exact in the f32 accumulator; the parity is its lowest bit.
+// (mt_combine_radix_kernel does the same products with one ds_read per set polynomial bit and output word: 8.8 GB of LDS
+// reads for the 340 windows of a two-layer walk pass, 0.21 ms; this form: 2.4 M MFMAs, ~0.06 ms.)
+//
+// Operand A (polynomials; row m = lane & 31, k half = lane >> 5) comes pre-expanded from global memory
+// (mt_pack_polys_kernel, 1 KiB per 64-bit k step).  Operand B for (lag tile J, k step ks) is the Hankel fragment
+//     lane (n, kb):  plane_b[32 (2 ks + kb + J) + n + t],  t = 0..31   =: R_d, d = 2 ks + J
+// which depends on 2 ks + J only: a register window of five R_d serves the five lag tiles of a wave and slides by two per
+// step, so a step is 5 MFMAs for 2 fragment loads.  A fragment is 32 consecutive nibbles of the plane's nibble stream
+// starting at nibble 32 (d + kb) + n: the workgroup keeps its slice of that stream in LDS in EIGHT copies, copy c shifted
+// by c nibbles, so that every lane reads four whole dwords (copy n & 7).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+constexpr int KS_TOTAL = 315;                 // 64-bit k steps: 312 (19 968 polynomial bits) padded to a multiple of 5 x parts
+constexpr int PLW = SEQ_PAD / 32;             // dwords per bit plane of an expanded sequence
+constexpr int JT = 20, JG = 5;                // 32-lag tiles (624 lags = 19.5 tiles), lag tiles per work item
+static_assert(SEQ_PAD % 32 == 0 && JT * 32 >= MT_N && JT == 4 * JG, "plane geometry: four waves x JG lag tiles");
+
+// 8 bits -> 8 fp4 nibbles (bit set -> 1.0 = 0x2), lowest bit in the lowest nibble
+__device__ __forceinline__ uint32_t bits_to_fp4(uint32_t byte) {
+    auto four = [](uint32_t n) { return (n | (n << 3) | (n << 6) | (n << 9)) & 0x1111u; };
+    return (four(byte & 15u) | (four((byte >> 4) & 15u) << 16)) << 1;
+}
+
+// polyA[ks][lane] = the 32 coefficients 64 ks + 32 (lane >> 5) + t of polynomial lane & 31 (rows >= `rows`: zero)
+__global__ __launch_bounds__(256) void mt_pack_polys_kernel(const uint32_t *__restrict__ polys, int rows, uint4 *__restrict__ polyA) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= KS_TOTAL * 64) return;
+    const int ks = idx >> 6, lane = idx & 63, m = lane & 31, w = 2 * ks + (lane >> 5);
+    const uint32_t word = (m < rows && w < MT_N) ? polys[(size_t)m * MT_N + w] : 0u;
+    polyA[idx] = make_uint4(bits_to_fp4(word & 255u), bits_to_fp4((word >> 8) & 255u), bits_to_fp4((word >> 16) & 255u),
+                            bits_to_fp4(word >> 24));
+}
+
+// planes[src][b][g] = bit b of the 32 words seq[src][32 g .. 32 g + 31] (word i -> bit i)
+__global__ __launch_bounds__(256) void mt_planes_kernel(const uint32_t *__restrict__ seq, uint32_t *__restrict__ planes) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t *s = seq + (size_t)blockIdx.y * SEQ_PAD;
+    uint32_t *pl = planes + (size_t)blockIdx.y * 32 * PLW;
+    for (int grp = blockIdx.x * 4 + wv; grp * 64 < SEQ_PAD; grp += gridDim.x * 4) {
+        const int i = grp * 64 + lane;
+        const uint32_t word = i < SEQ_PAD ? s[i] : 0u;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            const uint64_t m = __ballot((word >> b) & 1u);
+            if (lane == 0) {
+                pl[b * PLW + 2 * grp] = (uint32_t)m;
+                if (2 * grp + 1 < PLW) pl[b * PLW + 2 * grp + 1] = (uint32_t)(m >> 32);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ v16f_t bit_mfma(const v4i_t &a, const v4i_t &b, const v16f_t &c) {
+    const v8i_t A = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+    const v8i_t B = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+// One workgroup = (source, bit plane b, slice `part` of the polynomial bits); its four waves take five lag tiles each and share
+// the nibble stream in LDS and -- through the L1 -- the A fragments.  PLp[part][src][b][J][row] = the parities of this slice,
+// bit n = lag 32 J + n (plain stores: mt_jump_finish_kernel XORs the slices and turns the bit planes into words).
+__global__ __launch_bounds__(256, 2) void mt_jump_mfma_kernel(const uint32_t *__restrict__ planes, const uint4 *__restrict__ polyA,
+                                                              uint32_t *__restrict__ PLp, int nsrc, int parts, int steps) {
+    extern __shared__ uint32_t copies[];                     // [8][CW]
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6, n = lane & 31, kb = lane >> 5;
+    int item = blockIdx.x;
+    const int b = item & 31; item >>= 5;
+    const int src = item % nsrc, part = item / nsrc;
+    const int ks0 = part * steps, J0 = g * JG;
+    const int dmin = 2 * ks0;
+    const int CW = 4 * (2 * steps + JT + 1) + 8;             // dwords per copy: fragments d = dmin .. dmin + 2 steps + JT
+    // nibble stream of plane b from nibble 32 dmin on, eight shifts
+    const uint32_t *pl = planes + ((size_t)src * 32 + b) * PLW;
+    for (int m = tid; m < ((PS_MT_DEBUG & 1) ? 64 : CW); m += 256) {
+        const int p0 = 32 * dmin + 8 * m;                    // first plane bit of dword m (copy 0)
+        const uint32_t w0 = (p0 >> 5) < PLW ? pl[p0 >> 5] : 0u, w1 = ((p0 + 8) >> 5) < PLW ? pl[(p0 + 8) >> 5] : 0u;
+        const uint32_t e0 = bits_to_fp4((w0 >> (p0 & 31)) & 255u), e1 = bits_to_fp4((w1 >> ((p0 + 8) & 31)) & 255u);
+        copies[m] = e0;
+#pragma unroll
+        for (int c = 1; c < 8; ++c) copies[c * CW + m] = __builtin_amdgcn_alignbit(e1, e0, 4 * c);
+    }
+    __syncthreads();
+    const uint32_t *frag = copies + (n & 7) * CW + 4 * (J0 + kb) + (n >> 3);       // + 4 x for R_{dmin + J0 + x}
+    auto load_r = [&](int x) { const uint32_t *q = frag + 4 * x; return v4i_t{(int)q[0], (int)q[1], (int)q[2], (int)q[3]}; };
+    const uint4 *pa = polyA + (size_t)ks0 * 64 + lane;
+    auto load_a = [&](int u) { const uint4 v = pa[(size_t)u * 64]; return v4i_t{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; };
+
+    v16f_t acc[JG];
+#pragma unroll
+    for (int j = 0; j < JG; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    constexpr int PF = 10;                                   // A fragments in flight (k steps ahead)
+    v4i_t R[JG], A[PF];
+#pragma unroll
+    for (int j = 0; j < JG; ++j) R[j] = load_r(j);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) A[u] = load_a(u < steps ? u : 0);
+    for (int ub = 0; ub < steps; ub += PF) {
+#pragma unroll
+        for (int uu = 0; uu < PF; ++uu) {
+            if (ub + uu < steps) {                           // wave-uniform
+                // step u = ub + uu: lag tile jj uses R_{dmin + J0 + 2 u + jj} = slot (2 uu + jj) % JG (ub is a multiple of 5)
+                const v4i_t a = A[uu];
+#pragma unroll
+                for (int jj = 0; jj < JG; ++jj) {
+                    if (!(PS_MT_DEBUG & 8)) acc[jj] = bit_mfma(a, R[(2 * uu + jj) % JG], acc[jj]);
+                    else acc[jj][0] += __builtin_bit_cast(float, a[0] ^ R[(2 * uu + jj) % JG][0]);
+                    if (jj == 1) {    // slots 2 uu, 2 uu + 1 are free: the two fragments the next step adds (past the end: in range, unused)
+                        R[(2 * uu) % JG] = load_r(2 * (ub + uu) + JG);
+                        R[(2 * uu + 1) % JG] = load_r(2 * (ub + uu) + JG + 1);
+                    }
+                }
+                if (ub + PF + uu < steps && !(PS_MT_DEBUG & 2)) A[uu] = load_a(ub + PF + uu);
+            }
+        }
+    }
+    // parities, packed over the 32 lags of a tile: C col = lane & 31 (lag), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (polynomial)
+    uint32_t *out = PLp + ((((size_t)part * nsrc + src) * 32 + b) * JT + J0) * 32;
+#pragma unroll
+    for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint64_t m = __ballot(((int)acc[jj][r]) & 1);
+            if (n == 0 && (!(PS_MT_DEBUG & 4) || m == 0x123456789ull))
+                out[jj * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb] = kb ? (uint32_t)(m >> 32) : (uint32_t)m;
+        }
+}
+
+// PLp[0][i] ^= PLp[1..parts-1][i] (i over one slice's [nsrc][32][JT][32] dwords)
+__global__ __launch_bounds__(256) void mt_jump_reduce_kernel(uint32_t *__restrict__ PLp, int64_t slice, int parts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= slice) return;
+    uint32_t v = PLp[i];
+    for (int part = 1; part < parts; ++part) v ^= PLp[part * slice + i];
+    PLp[i] = v;
+}
+
+// plain[tgt][j] = the word whose bit b is bit (j & 31) of PL[src][b][j >> 5][m]; tgt = src * src_step + (m + 1) * m_step
+__global__ __launch_bounds__(256) void mt_jump_finish_kernel(const uint32_t *__restrict__ PL, int nsrc, int rows, int64_t src_step,
+                                                             int64_t m_step, int64_t K, uint32_t *__restrict__ plain) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)nsrc * rows * MT_N) return;
+    const int j = (int)(idx % MT_N), m = (int)((idx / MT_N) % rows), src = (int)(idx / ((int64_t)MT_N * rows));
+    const int64_t tgt = src * src_step + (m + 1) * m_step;
+    if (tgt >= K) return;
+    const uint32_t *p = PL + (((size_t)src * 32) * JT + (j >> 5)) * 32 + m;
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) w |= ((p[(size_t)b * JT * 32] >> (j & 31)) & 1u) << b;
+    plain[tgt * MT_N + j] = w;
+}
+
+__global__ __launch_bounds__(256) void mt_fold_kernel(const uint32_t *parts, uint32_t *plain) {      // JP parts -> plain window
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= MT_N) return;
+    uint32_t v = 0;
+#pragma unroll
+    for (int p = 0; p < JP; ++p) v ^= parts[p * MT_N + i];
+    plain[i] = v;
+}
+
 // chunk c (window = states[c]) holds stream words [1 + (c0 + c) * CHUNK, +CHUNK); raw[w - w_lo] for w in [w_lo, w_hi)
-__global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, int64_t c0, int64_t w_lo, int64_t w_hi,
-                                                       uint32_t *raw) {
+// A chunk is a serial chain of 210 block updates (LDS round trip + barrier each).  The loop is unrolled by two so that the
+// two LDS images have constant addresses, the block's position against [w_lo, w_hi) is scalar work, and the chain ends where
+// the wanted words end.  (Several chunks per workgroup behind common barriers were slower: 109 / 142 us for 2 / 4 against 99.)
+__global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, int nparts, int64_t c0, int64_t w_lo,
+                                                       int64_t w_hi, uint32_t *raw) {
     __shared__ uint32_t mt[2][MT_N];
     const int t = threadIdx.x;
     const int64_t wbase = 1 + (c0 + blockIdx.x) * CHUNK;
-    for (int i = t; i < MT_N; i += 256) mt[0][i] = load_window_word(states + (size_t)blockIdx.x * JP * MT_N, i);
-    __syncthreads();
-    int cur = 0;
-    for (int64_t off = 0; off < CHUNK; off += MT_N) {
-        const int take = (CHUNK - off) < MT_N ? (int)(CHUNK - off) : MT_N;
-        for (int i = t; i < take; i += 256) {
-            const int64_t w = wbase + off + i;
-            if (w >= w_lo && w < w_hi) raw[w - w_lo] = mt[cur][i];
-        }
-        if (off + MT_N < CHUNK) {
-            next_block(mt[cur], mt[cur ^ 1], t);
-            cur ^= 1;
-        }
+    const int64_t end = (w_hi - wbase) < CHUNK ? (w_hi - wbase) : CHUNK;      // words of this chunk that anybody wants
+    auto put = [&](int64_t off, int i, uint32_t v) {          // word i of the block that starts `off` words into the chunk
+        const int64_t w = wbase + off + i;
+        if (off + i < end && w >= w_lo) raw[w - w_lo] = v;
+    };
+    for (int i = t; i < MT_N; i += 256) {
+        const uint32_t v = load_window_word(states + (size_t)blockIdx.x * nparts * MT_N, nparts, i);
+        mt[0][i] = v;
+        put(0, i, v);
     }
+    __syncthreads();
+    auto step = [&](const uint32_t *o, uint32_t *n, int64_t off) {
+        const int64_t w0 = wbase + off;
+        if (off + MT_N <= end && w0 >= w_lo) {                 // whole block wanted (scalar test): no per-word tests
+            uint32_t *dst = raw + (w0 - w_lo);
+            next_block_emit(o, n, t, [&](int i, uint32_t v) { if (!(PS_MT_DEBUG & 16) || v == 0x12345u) dst[i] = v; });
+        } else {
+            next_block_emit(o, n, t, [&](int i, uint32_t v) { put(off, i, v); });
+        }
+    };
+    int64_t off = MT_N;
+    for (; off + MT_N < end; off += 2 * MT_N) {
+        step(mt[0], mt[1], off);
+        step(mt[1], mt[0], off + MT_N);
+    }
+    if (off < end) step(mt[0], mt[1], off);
 }
 
 __global__ void mt_raw_to_double_kernel(const uint32_t *raw, int64_t w_lo, int64_t skip, int64_t n, double *out) {
@@ -347,7 +564,7 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
     uint32_t *cur = tmpA, *nxt = tmpB;
     for (int b = 0; (p.c0 >> b) != 0; ++b) {
         if (!((p.c0 >> b) & 1)) continue;
-        hipLaunchKernelGGL(mt_expand_kernel, dim3(1), dim3(256), 0, st, cur, seqs);
+        hipLaunchKernelGGL(mt_expand_kernel, dim3(1), dim3(256), 0, st, cur, JP, (int64_t)WSZ, seqs);
         PS_CHECK_LAUNCH();
         hipLaunchKernelGGL(mt_combine_kernel, dim3(JP), dim3(192), 0, st, seqs, jump_polys + (size_t)(CHUNK_LOG2 + b) * MT_N, nxt);
         PS_CHECK_LAUNCH();
@@ -356,13 +573,75 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
     if (hipMemcpyAsync(states, cur, WSZ * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
     // 3. chunk windows: radix-32 rounds (window j * have + r = jump_{j * have chunks}(window r), j = 1..31) when the
     //    multiplier polynomials are given -- two rounds instead of eight serial expansions for 180 chunks -- else doubling
-    if (radix_polys && radix_levels > 0) {
+    bool plain_states = false;
+    uint32_t *plainS = nullptr;
+    if (radix_polys && radix_levels >= 2 && K > 32 && K <= 1024) {
+        // two radix-32 rounds on the matrix cores, big strides first: round A makes the windows 32 j (j = 1..JA) from window 0
+        // (polynomials of level 1), round B the windows 32 a + j (j = 1..31) from the windows 32 a, a = 0..JA (level 0): every
+        // product of round B shares its source with 30 others, which is what fills the 32 rows of the MFMA
+        const int JA = (int)((K - 1) / 32), nsrcB = JA + 1;
+        char *q = reinterpret_cast<char *>(seqs);
+        const char *q_end = q + align256((size_t)(K / 2 + 2) * SEQ_PAD * 4);
+        uint32_t *seqM = reinterpret_cast<uint32_t *>(q);      q += align256((size_t)nsrcB * SEQ_PAD * 4);
+        uint32_t *planes = reinterpret_cast<uint32_t *>(q);    q += align256((size_t)nsrcB * 32 * PLW * 4);
+        uint4 *polyA0 = reinterpret_cast<uint4 *>(q);          q += align256((size_t)KS_TOTAL * 64 * 16);
+        uint4 *polyA1 = reinterpret_cast<uint4 *>(q);          q += align256((size_t)KS_TOTAL * 64 * 16);
+        plainS = reinterpret_cast<uint32_t *>(q);              q += align256((size_t)K * MT_N * 4);
+        // parity planes of every polynomial slice: in the JP-part window store, unused (but for window 0) in this mode
+        constexpr int PARTS_A = 21, PARTS_B = 7;
+        uint32_t *PLp = states + WSZ;
+        const bool pl_fits = (size_t)PARTS_B * nsrcB * 32 * JT * 32 <= (size_t)(K - 1) * WSZ && (size_t)PARTS_A * 32 * JT * 32 <= (size_t)(K - 1) * WSZ;
+        if (q <= q_end && pl_fits) {
+            static bool attr_done[64] = {};
+            int devid = 0;
+            if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PS_ELAUNCH;
+            if (!attr_done[devid]) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(mt_jump_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        64 * 1024) != hipSuccess) return PS_ELAUNCH;
+                attr_done[devid] = true;
+            }
+            const unsigned pk = (KS_TOTAL * 64 + 255) / 256;
+            hipLaunchKernelGGL(mt_pack_polys_kernel, dim3(pk), dim3(256), 0, st, radix_polys + (size_t)1 * 31 * MT_N, JA, polyA1);
+            PS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(mt_pack_polys_kernel, dim3(pk), dim3(256), 0, st, radix_polys, 31, polyA0);
+            PS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(mt_fold_kernel, dim3(3), dim3(256), 0, st, states, plainS);
+            PS_CHECK_LAUNCH();
+            auto round = [&](int nsrc, const uint4 *polyA, int rows, int parts, int64_t src_step, int64_t m_step) -> int {
+                // sources: the plain windows src * 32 (round A: window 0 only)
+                hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)nsrc), dim3(256), 0, st, plainS, 1, (int64_t)32 * MT_N, seqM);
+                PS_CHECK_LAUNCH();
+                hipLaunchKernelGGL(mt_planes_kernel, dim3((SEQ_PAD / 64 + 4) / 4, (unsigned)nsrc), dim3(256), 0, st, seqM, planes);
+                PS_CHECK_LAUNCH();
+                const int steps = KS_TOTAL / parts;
+                const size_t lds = (size_t)8 * (4 * (2 * steps + JT + 1) + 8) * 4;
+                hipLaunchKernelGGL(mt_jump_mfma_kernel, dim3((unsigned)(nsrc * 32 * parts)), dim3(256), lds, st, planes, polyA, PLp, nsrc,
+                                   parts, steps);
+                PS_CHECK_LAUNCH();
+                const int64_t total = (int64_t)nsrc * rows * MT_N;
+                const int64_t slice = (int64_t)nsrc * 32 * JT * 32;
+                hipLaunchKernelGGL(mt_jump_reduce_kernel, dim3((unsigned)ps_cdiv(slice, 256)), dim3(256), 0, st, PLp, slice, parts);
+                PS_CHECK_LAUNCH();
+                hipLaunchKernelGGL(mt_jump_finish_kernel, dim3((unsigned)ps_cdiv(total, 256)), dim3(256), 0, st, PLp, nsrc, rows, src_step,
+                                   m_step, K, plainS);
+                PS_CHECK_LAUNCH();
+                return PS_OK;
+            };
+            int rc = round(1, polyA1, JA, PARTS_A, 0, 32);       // 672 short workgroups: the round is one item deep
+            if (rc != PS_OK) return rc;
+            rc = round(nsrcB, polyA0, 31, PARTS_B, 32, 1);
+            if (rc != PS_OK) return rc;
+            plain_states = true;
+        }
+    }
+    if (plain_states) {
+    } else if (radix_polys && radix_levels > 0) {
         int lvl = 0;
         for (int64_t have = 1; have < K; have *= 32, ++lvl) {
             if (lvl >= radix_levels) return PS_EUNSUPPORTED;
             const int64_t nsrc = (K - have) < have ? (K - have) : have;
             const int64_t jmax = ((K - 1) / have) < 31 ? ((K - 1) / have) : 31;
-            hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)nsrc), dim3(256), 0, st, states, seqs);
+            hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)nsrc), dim3(256), 0, st, states, JP, (int64_t)WSZ, seqs);
             PS_CHECK_LAUNCH();
             hipLaunchKernelGGL(mt_combine_radix_kernel, dim3((unsigned)(nsrc * JP), (unsigned)jmax), dim3(192), 0, st, seqs,
                                radix_polys + (size_t)lvl * 31 * MT_N, states, have, K);
@@ -372,7 +651,7 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
         for (int m = 0; ((int64_t)1 << m) < K; ++m) {
             const int64_t have = (int64_t)1 << m;
             const int64_t make = (K - have) < have ? (K - have) : have;
-            hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)make), dim3(256), 0, st, states, seqs);
+            hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)make), dim3(256), 0, st, states, JP, (int64_t)WSZ, seqs);
             PS_CHECK_LAUNCH();
             hipLaunchKernelGGL(mt_combine_kernel, dim3((unsigned)(make * JP)), dim3(192), 0, st, seqs,
                                jump_polys + (size_t)(CHUNK_LOG2 + m) * MT_N, states + (size_t)have * WSZ);
@@ -380,7 +659,8 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
         }
     }
     // 4. chunks -> raw words; word 0 separately
-    hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)K), dim3(256), 0, st, states, p.c0, p.w_lo, p.w_hi, raw);
+    if (plain_states) hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)K), dim3(256), 0, st, plainS, 1, p.c0, p.w_lo, p.w_hi, raw);
+    else hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)K), dim3(256), 0, st, states, JP, p.c0, p.w_lo, p.w_hi, raw);
     PS_CHECK_LAUNCH();
     if (p.w_lo == 0)
         if (hipMemcpyAsync(raw, word0, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
