@@ -12,7 +12,9 @@
 // with g(t) = t^(2^m) mod phi(t) (pinsage_hip/mtjump.py), the window 2^m words ahead is the XOR of the windows
 // at the offsets i with g_i = 1 -- one workgroup expands 34 blocks of the sequence to global memory, then 24
 // workgroups each XOR the windows selected by 1/24 of the polynomial (the 24 partial windows are XORed by whoever
-// reads the window next).  Chunk windows are produced by doubling (1 -> 2 -> 4 ... windows per round).
+// reads the window next).  Chunk windows are produced by doubling (1 -> 2 -> 4 ... windows per round), by radix-32 rounds
+// (31 multiplier polynomials per round), or -- more than 32 chunks, the walk sampler's case -- by two radix-32 rounds whose
+// window products run on the matrix cores ("jump products on the matrix cores" below).
 // Without polynomials (or for short requests) a single workgroup generates the stream serially.
 #include "ps_common.h"
 
@@ -292,10 +294,11 @@ __device__ __forceinline__ v16f_t bit_mfma(const v4i_t &a, const v4i_t &b, const
 }
 
 // One workgroup = (source, bit plane b, slice `part` of the polynomial bits); its four waves take five lag tiles each and share
-// the nibble stream in LDS and -- through the L1 -- the A fragments.  PLp[part][src][b][J][row] = the parities of this slice,
-// bit n = lag 32 J + n (plain stores: mt_jump_finish_kernel XORs the slices and turns the bit planes into words).
+// the nibble stream in LDS and -- through the L1 -- the A fragments.  PLp[part][src][b][J][lane] = the parities of this slice
+// as the MFMA leaves them: bit r of entry `lane` = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), lag 32 J + (lane & 31) (plain
+// stores: mt_jump_reduce_kernel XORs the slices, mt_jump_finish_kernel turns the bit planes into words).
 __global__ __launch_bounds__(256, 2) void mt_jump_mfma_kernel(const uint32_t *__restrict__ planes, const uint4 *__restrict__ polyA,
-                                                              uint32_t *__restrict__ PLp, int nsrc, int parts, int steps) {
+                                                              uint16_t *__restrict__ PLp, int nsrc, int parts, int steps) {
     extern __shared__ uint32_t copies[];                     // [8][CW]
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6, n = lane & 31, kb = lane >> 5;
     int item = blockIdx.x;
@@ -350,39 +353,43 @@ __global__ __launch_bounds__(256, 2) void mt_jump_mfma_kernel(const uint32_t *__
             }
         }
     }
-    // parities, packed over the 32 lags of a tile: C col = lane & 31 (lag), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (polynomial)
-    uint32_t *out = PLp + ((((size_t)part * nsrc + src) * 32 + b) * JT + J0) * 32;
+    // parities: C col = lane & 31 (lag), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (polynomial).  Every lane packs the
+    // parities of its 16 rows into 16 bits and stores them as they lie (one coalesced 128-byte store per lag tile);
+    // mt_jump_finish_kernel picks bit r of lane (lag, row half) -- 16 ballots per tile cost 6 x the instructions
+    uint16_t *out = PLp + ((((size_t)part * nsrc + src) * 32 + b) * JT + J0) * 64 + lane;
 #pragma unroll
-    for (int jj = 0; jj < JG; ++jj)
+    for (int jj = 0; jj < JG; ++jj) {
+        uint32_t bits = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint64_t m = __ballot(((int)acc[jj][r]) & 1);
-            if (n == 0 && (!(PS_MT_DEBUG & 4) || m == 0x123456789ull))
-                out[jj * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb] = kb ? (uint32_t)(m >> 32) : (uint32_t)m;
-        }
+        for (int r = 0; r < 16; ++r) bits |= (((uint32_t)(int)acc[jj][r]) & 1u) << r;
+        if (!(PS_MT_DEBUG & 4) || bits == 0x12345u) out[jj * 64] = (uint16_t)bits;
+    }
 }
 
-// PLp[0][i] ^= PLp[1..parts-1][i] (i over one slice's [nsrc][32][JT][32] dwords)
-__global__ __launch_bounds__(256) void mt_jump_reduce_kernel(uint32_t *__restrict__ PLp, int64_t slice, int parts) {
+// PLp[0][i] ^= PLp[1..parts-1][i] (i over one slice's [nsrc][32][JT][64] 16-bit entries, two per thread)
+__global__ __launch_bounds__(256) void mt_jump_reduce_kernel(uint32_t *__restrict__ PLp, int64_t slice_dwords, int parts) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= slice) return;
+    if (i >= slice_dwords) return;
     uint32_t v = PLp[i];
-    for (int part = 1; part < parts; ++part) v ^= PLp[part * slice + i];
+#pragma unroll 8
+    for (int part = 1; part < parts; ++part) v ^= PLp[part * slice_dwords + i];     // (unrolled: the loads of a batch in flight together)
     PLp[i] = v;
 }
 
-// plain[tgt][j] = the word whose bit b is bit (j & 31) of PL[src][b][j >> 5][m]; tgt = src * src_step + (m + 1) * m_step
-__global__ __launch_bounds__(256) void mt_jump_finish_kernel(const uint32_t *__restrict__ PL, int nsrc, int rows, int64_t src_step,
+// plain[tgt][j]: bit b = parity of polynomial row m at lag j in plane b = bit r of PL[src][b][j >> 5][32 kb + (j & 31)] with
+// m = (r & 3) + 8 (r >> 2) + 4 kb; tgt = src * src_step + (m + 1) * m_step
+__global__ __launch_bounds__(256) void mt_jump_finish_kernel(const uint16_t *__restrict__ PL, int nsrc, int rows, int64_t src_step,
                                                              int64_t m_step, int64_t K, uint32_t *__restrict__ plain) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)nsrc * rows * MT_N) return;
     const int j = (int)(idx % MT_N), m = (int)((idx / MT_N) % rows), src = (int)(idx / ((int64_t)MT_N * rows));
     const int64_t tgt = src * src_step + (m + 1) * m_step;
     if (tgt >= K) return;
-    const uint32_t *p = PL + (((size_t)src * 32) * JT + (j >> 5)) * 32 + m;
+    const int r = (m & 3) | ((m >> 3) << 2), kb = (m >> 2) & 1;
+    const uint16_t *p = PL + (((size_t)src * 32) * JT + (j >> 5)) * 64 + 32 * kb + (j & 31);
     uint32_t w = 0;
 #pragma unroll
-    for (int b = 0; b < 32; ++b) w |= ((p[(size_t)b * JT * 32] >> (j & 31)) & 1u) << b;
+    for (int b = 0; b < 32; ++b) w |= (((uint32_t)p[(size_t)b * JT * 64] >> r) & 1u) << b;
     plain[tgt * MT_N + j] = w;
 }
 
@@ -589,17 +596,9 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
         plainS = reinterpret_cast<uint32_t *>(q);              q += align256((size_t)K * MT_N * 4);
         // parity planes of every polynomial slice: in the JP-part window store, unused (but for window 0) in this mode
         constexpr int PARTS_A = 21, PARTS_B = 7;
-        uint32_t *PLp = states + WSZ;
+        uint16_t *PLp = reinterpret_cast<uint16_t *>(states + WSZ);
         const bool pl_fits = (size_t)PARTS_B * nsrcB * 32 * JT * 32 <= (size_t)(K - 1) * WSZ && (size_t)PARTS_A * 32 * JT * 32 <= (size_t)(K - 1) * WSZ;
         if (q <= q_end && pl_fits) {
-            static bool attr_done[64] = {};
-            int devid = 0;
-            if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PS_ELAUNCH;
-            if (!attr_done[devid]) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(mt_jump_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        64 * 1024) != hipSuccess) return PS_ELAUNCH;
-                attr_done[devid] = true;
-            }
             const unsigned pk = (KS_TOTAL * 64 + 255) / 256;
             hipLaunchKernelGGL(mt_pack_polys_kernel, dim3(pk), dim3(256), 0, st, radix_polys + (size_t)1 * 31 * MT_N, JA, polyA1);
             PS_CHECK_LAUNCH();
@@ -619,8 +618,9 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
                                    parts, steps);
                 PS_CHECK_LAUNCH();
                 const int64_t total = (int64_t)nsrc * rows * MT_N;
-                const int64_t slice = (int64_t)nsrc * 32 * JT * 32;
-                hipLaunchKernelGGL(mt_jump_reduce_kernel, dim3((unsigned)ps_cdiv(slice, 256)), dim3(256), 0, st, PLp, slice, parts);
+                const int64_t slice = (int64_t)nsrc * 32 * JT * 32;                     // dwords (two 16-bit entries each)
+                hipLaunchKernelGGL(mt_jump_reduce_kernel, dim3((unsigned)ps_cdiv(slice, 256)), dim3(256), 0, st,
+                                   reinterpret_cast<uint32_t *>(PLp), slice, parts);
                 PS_CHECK_LAUNCH();
                 hipLaunchKernelGGL(mt_jump_finish_kernel, dim3((unsigned)ps_cdiv(total, 256)), dim3(256), 0, st, PLp, nsrc, rows, src_step,
                                    m_step, K, plainS);
@@ -673,7 +673,7 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
     }
     // 6. the state numpy would be left in
     if (p.key_w >= 0) {
-        hipLaunchKernelGGL(mt_final_state_kernel, dim3(1), dim3(256), 0, st, raw, p.w_lo, p.key_w, p.pos_out, state_out, pos_out);
+        hipLaunchKernelGGL(mt_final_state_kernel, dim3(1), dim3(640), 0, st, raw, p.w_lo, p.key_w, p.pos_out, state_out, pos_out);
         PS_CHECK_LAUNCH();
     } else {
         if (hipMemcpyAsync(state_out, state_in, MT_N * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
