@@ -215,7 +215,7 @@ def main():
         sync_all()
         elapsed_instr = time.perf_counter() - t1
         nv.set_timer(None)
-        pipe.overlap_sampling = True
+        pipe.overlap_sampling = False
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
