@@ -29,15 +29,6 @@
 #ifndef PS_GEMM_SPREAD
 #define PS_GEMM_SPREAD 1
 #endif
-#ifndef PS_GEMM_W2
-#define PS_GEMM_W2 0       // 1: permuting stash by ds_write2_b32 from inline asm (no v_mov): measured equal, its 8-byte writes conflict
-#endif
-#ifndef PS_GEMM_PRIO
-#define PS_GEMM_PRIO 0
-#endif
-#ifndef PS_GEMM_STAGGER
-#define PS_GEMM_STAGGER 0
-#endif
 
 #if PS_GEMM_DEBUG & 64      // timeline experiment (tools/gemm_trace.py): per wave HW_ID, XCC_ID and s_memtime stamps
 __device__ unsigned long long ps_gemm_trace_buf[4096 * 4 * 48];
@@ -134,22 +125,13 @@ __device__ __forceinline__ float transpose_sum32(float (&v)[NV], int lane) {
 #undef PS_DPP_ADD
 
 // One (row, 8-k group) item, registers lo = k 0..3, hi = k 4..7, into its LDS image [lane half h][4] = k 2 t + h.
-// ds_write2_b32 takes its two dwords from two unrelated registers, so the permutation costs no register moves (40 v_mov
-// per thread and K step between the two barriers, where nothing hides them: knock-out 15 of 166 us).
+// (Writing the permutation with ds_write2_b32 from two unrelated registers needs no moves at all but measured equal: its
+// 8-byte writes conflict 4-way.)
 template <bool PIN>
 __device__ __forceinline__ void stash_item(float *d, f32x4 lo, f32x4 hi) {
-#if PS_GEMM_W2
-    const uint32_t a = (uint32_t)(uintptr_t)d;       // LDS byte address
-    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\t"
-                 "ds_write2_b32 %0, %3, %4 offset0:2 offset1:3\n\t"
-                 "ds_write2_b32 %0, %5, %6 offset0:4 offset1:5\n\t"
-                 "ds_write2_b32 %0, %7, %8 offset0:6 offset1:7"
-                 :: "v"(a), "v"(lo[0]), "v"(lo[2]), "v"(hi[0]), "v"(hi[2]), "v"(lo[1]), "v"(lo[3]), "v"(hi[1]), "v"(hi[3]) : "memory");
-#else
     if (PIN) asm volatile("" : "+v"(lo), "+v"(hi));  // pins the moves behind the barrier (else: vmcnt waits among the MFMAs)
     *reinterpret_cast<f32x4 *>(d) = f32x4{lo[0], lo[2], hi[0], hi[2]};
     *reinterpret_cast<f32x4 *>(d + 4) = f32x4{lo[1], lo[3], hi[1], hi[3]};
-#endif
 }
 
 // FAST: every operand is 16-B aligned with K % BK == 0 -> unconditional float4 loads (rows past the end are
@@ -176,41 +158,12 @@ __global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(Gem
     const int n0 = blockIdx.y * BN;
     const int li = lane & 31, lh = lane >> 5;
 
-#if PS_GEMM_PRIO == 1
-    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2);
-#elif PS_GEMM_PRIO == 2
-    {   // the wave slot (HW_ID.wave_id) of the block's first wave: the two blocks that share a CU sit in different slots
-        if (tid == 0) reinterpret_cast<volatile int *>(sRed)[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1;
-        __syncthreads();
-        const int odd = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile int *>(sRed)[0]);
-        __syncthreads();
-        if (odd) __builtin_amdgcn_s_setprio(2);
-    }
-#endif
 #if PS_GEMM_DEBUG & 64
     if (lane == 0 && blockIdx.x < 4096) {
         ps_gemm_trace_buf[((size_t)blockIdx.x * 4 + (wv & 3)) * 48 + 46] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);    // HW_ID
         ps_gemm_trace_buf[((size_t)blockIdx.x * 4 + (wv & 3)) * 48 + 47] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);   // XCC_ID
     }
     int trace_step = 0;
-#endif
-#if PS_GEMM_STAGGER
-    // the blocks of the first round all start together, run the same program at the same speed and therefore reach their
-    // epilogues together: the whole chip stops multiplying and writes 33 MB at once (tools/gemm_trace.py: the epilogue takes
-    // 22 % of a block's life, mostly store back-pressure).  Holding back the second block of every CU de-phases the two
-    // residents for the rest of the launch (their successors inherit the offset); the first block has the MFMA pipe to itself
-    // meanwhile, so nothing is lost.
-    if (blockIdx.x < 2 * 256 && gridDim.x > 2 * 256) {
-        const int slot = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 4)) & 1;
-        if (tid == 0) reinterpret_cast<volatile int *>(sRed)[0] = slot;
-        __syncthreads();
-        const int held = reinterpret_cast<volatile int *>(sRed)[0];
-        __syncthreads();
-        if (held) {
-            const unsigned long long t0 = __builtin_readcyclecounter();
-            while (__builtin_readcyclecounter() - t0 < (unsigned long long)PS_GEMM_STAGGER) __builtin_amdgcn_s_sleep(64);
-        }
-    }
 #endif
     PS_TRACE(0);
     f32x16 acc[TM][TN];
@@ -293,7 +246,6 @@ __global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(Gem
 #endif
             if (!(PS_GEMM_DEBUG & 4) || k0 == 0) __syncthreads();           // previous step's fragment reads are done
             if (!(PS_GEMM_DEBUG & 2) || k0 == 0) stash();
-            if (PS_GEMM_W2) __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the asm's LDS writes have landed
             if (!(PS_GEMM_DEBUG & 4) || k0 == 0) __syncthreads();
 #if PS_GEMM_DEBUG & 64
             PS_TRACE(3 + 2 * trace_step);                                   // image published: MFMA stream starts

@@ -13,20 +13,23 @@ from model.pinsage import PinSage
 
 ap = argparse.ArgumentParser(); ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--graph", action="store_true", help="also time the step replayed from ONE captured hipGraph")
+ap.add_argument("--rng", default="philox", choices=["philox", "numpy"])
+ap.add_argument("--rank", type=int, default=0, help="which rank's shard this GPU plays (numpy mode: its slice of the RNG stream)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 U, M, R = synth.ML25M["num_users"], synth.ML25M["num_items"], synth.ML25M["num_ratings"]
 ei, ew = synth.bipartite_ratings(U, M, R, device=dev)
 g = DeviceGraph(ei, ew); del ei, ew
-smp = RandomWalkSampler.from_graph(g, 2, 100, rng="philox", seed=42)
+smp = RandomWalkSampler.from_graph(g, 2, 100, rng=a.rng, seed=42)
 model = PinSage(128, 256, 256, 2).to(dev).eval()
 P = {k: v.detach().float().contiguous() for k, v in model.state_dict().items()}
 x_full = torch.randn(M, 128, device=dev)
 A = torch.from_numpy(lsh_rotation_matrix(256, 512)).to(dev)
 for world in [int(w) for w in a.worlds.split(",")]:
     pipe = S.ShardedPinSage(P, 2, smp, M)
-    pipe.world, pipe.rank = world, 0
-    pipe.lo, pipe.hi, pipe.chunk = S.shard_range(M, 0, world)
+    rank = min(a.rank, world - 1)
+    pipe.world, pipe.rank = world, rank
+    pipe.lo, pipe.hi, pipe.chunk = S.shard_range(M, rank, world)
     full = {}
 
     def fake_gather(t, chunk, group=None, _w=world):
@@ -42,6 +45,9 @@ for world in [int(w) for w in a.worlds.split(",")]:
     nq_local = 10000 // world
 
     def step():
+        if a.rng == "numpy":
+            import numpy as np
+            np.random.seed(42)
         emb = pipe.embed(x_loc, 10, x_full=x_full if world > 1 else None)
         pipe.build_index(emb, A)
         return pipe.search(emb[:nq_local], 11)
@@ -73,6 +79,6 @@ for world in [int(w) for w in a.worlds.split(",")]:
             for _ in range(50):
                 gr.replay()
             torch.cuda.synchronize(); gms = (time.perf_counter() - t0) / 50 * 1e3
-    print(f"world {world}: {ms:.3f} ms per step (compute only, rank 0 of {world}; host enqueue {host_ms:.3f} ms"
+    print(f"world {world}: {ms:.3f} ms per step (compute only, rank {rank} of {world}, rng {a.rng}; host enqueue {host_ms:.3f} ms"
           + (f"; replayed from one hipGraph {gms:.3f} ms" if gms is not None else "") + "); "
           + ", ".join(f"{k[3:]} {v['ms'] / 10:.3f}" for k, v in ks.items()), flush=True)
