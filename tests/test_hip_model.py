@@ -409,7 +409,7 @@ def test_graphconv_edge_branch_hip_vs_torch():
 
 @pytest.mark.parametrize("P,k", [(2, 11), (5, 11), (8, 11), (20, 11), (30, 11), (3, 1), (4, 64)])
 def test_topk_merge_vs_lexsort(P, k):
-    """ps_topk_merge over P candidate lists (rank merge for P*k <= 256, selection kernel beyond) vs a numpy
+    """ps_topk_merge over P candidate lists (16-lane selection for P*k <= 256, one wave per query beyond) vs a numpy
     (distance, id) sort; lists may be short (-1 / INT32_MAX padding) and distances tie across lists."""
     from pinsage_hip import dense
     rs = np.random.RandomState(P * 100 + k)
