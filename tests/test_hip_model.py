@@ -224,7 +224,10 @@ def test_device_mt19937_matches_numpy():
     skipped prefixes (multi-GPU shards) and the advanced global state."""
     from pinsage_hip import dense
     cases = [(42, 0, 5000, 0), (0, 3, 1249, 0), (123, 311, 300000, 0), (7, 1, 1, 0), (5, 10, 200000, 123457),
-             (11, 77, 4096, 5000000), (13, 624, 131072, 0), (17, 5, 1 << 20, 1 << 22), (9, 0, 11809400, 0)]
+             (11, 77, 4096, 5000000), (13, 624, 131072, 0), (17, 5, 1 << 20, 1 << 22), (9, 0, 11809400, 0),
+             # chunk windows by matrix-core jump products (33..1024 chunks): after a skipped prefix (base jump first), 33 chunks
+             # (one source in the second round), and the largest table that path serves (1008 chunks; beyond: radix rounds)
+             (19, 3, 5_000_000, 5_000_000), (21, 0, 2_150_000, 0), (23, 1, 66_000_000, 0), (29, 0, 68_000_000, 0)]
     for seed, burn, n, skip in cases:
         np.random.seed(seed)
         np.random.random_sample(burn)
