@@ -211,7 +211,9 @@ int ps_topk_merge(const int32_t *dist_in, const int64_t *ids_in, int P, int64_t 
                   int32_t *dist, int64_t *ids, ps_stream_t stream);
 
 /* ---- a11: exact search (inference.py:112-118, utils/evaluation.py:106-132) --------------------
- * sim = E[q] . E^T ; optionally sim[q] = -inf ; top-k descending.  vals float[nq,k], ids int64[nq,k]. */
+ * sim = E[q] . E^T ; optionally sim[q] = -inf ; top-k descending.  vals float[nq,k], ids int64[nq,k].  Any k >= 1
+ * (k > 32: further sweeps over the similarity row, each admitting the keys after the last one emitted; k > N pads with
+ * (-inf, -1)); the same holds for ps_l2_topk. */
 size_t ps_dot_topk_workspace_bytes(int64_t nq, int64_t N, int D, int k);
 int ps_dot_topk(const float *E, int64_t N, int D, const int64_t *qidx, int64_t nq, int k, int exclude_self,
                 float *vals, int64_t *ids, void *workspace, size_t workspace_bytes, ps_stream_t stream);

@@ -36,58 +36,69 @@ __device__ __forceinline__ float key_value(uint32_t kk) {
 // dist = |q|^2 + |x|^2 - 2 q.x, optionally restricted to the items whose inverted list (assign) is probed.
 template <int MODE>
 __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__ sims, int64_t N, int64_t rows,
-                                                       const int64_t *__restrict__ qidx, int exclude_self, int k,
+                                                       const int64_t *__restrict__ qidx, int exclude_self, int k, int kcap,
                                                        const float *__restrict__ qn, const float *__restrict__ xn,
                                                        const int32_t *__restrict__ assign,
                                                        const uint32_t *__restrict__ probe, int words,
                                                        float *__restrict__ vals, int64_t *__restrict__ ids) {
-    extern __shared__ uint64_t skeys[];   // [4 waves][k][64]
+    extern __shared__ uint64_t skeys[];   // [4 waves][kcap][64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint64_t *col = skeys + (size_t)wv * k * 64 + lane;
+    uint64_t *col = skeys + (size_t)wv * kcap * 64 + lane;
     const int64_t row = (int64_t)blockIdx.x * 4 + wv;
     if (row >= rows) return;
     const float *s = sims + row * N;
     const int64_t self = exclude_self ? qidx[row] : -1;
-    for (int p = 0; p < k; ++p) col[p * 64] = EMPTY_KEY;
-    uint64_t worst = EMPTY_KEY;
-    int filled = 0;
     const float qnr = (MODE == 1) ? qn[row] : 0.f;
-    for (int64_t j = lane; j < N; j += 64) {
-        float v = s[j];
-        if (MODE == 1) {
-            if (assign) {
-                const int32_t a = assign[j];
-                if (!((probe[row * words + (a >> 5)] >> (a & 31)) & 1u)) continue;   // list not probed
+    // k > kcap (the per-lane columns of one sweep fill the LDS at 32 keys): further sweeps over the row, each admitting only
+    // keys AFTER the last one emitted -- keys are unique (id in the low word), so the sweeps partition the order exactly
+    uint64_t after = 0;
+    bool first = true, dry = false;
+    for (int base = 0; base < k; base += kcap) {
+        const int kk = (k - base) < kcap ? (k - base) : kcap;
+        for (int p = 0; p < kk; ++p) col[p * 64] = EMPTY_KEY;
+        uint64_t worst = EMPTY_KEY;
+        int filled = 0;
+        if (!dry)
+            for (int64_t j = lane; j < N; j += 64) {
+                float v = s[j];
+                if (MODE == 1) {
+                    if (assign) {
+                        const int32_t a = assign[j];
+                        if (!((probe[row * words + (a >> 5)] >> (a & 31)) & 1u)) continue;   // list not probed
+                    }
+                    v = (qnr + xn[j]) - 2.f * v;
+                }
+                if (j == self) v = -INFINITY;
+                const uint64_t key = ((uint64_t)(MODE == 1 ? ~desc_key(v) : desc_key(v)) << 32) | (uint32_t)j;
+                if (!first && key <= after) continue;
+                if (key < worst) {
+                    int p = filled < kk ? filled : kk - 1;
+                    while (p > 0 && col[(p - 1) * 64] > key) { col[p * 64] = col[(p - 1) * 64]; --p; }
+                    col[p * 64] = key;
+                    if (filled < kk) ++filled;
+                    if (filled == kk) worst = col[(kk - 1) * 64];
+                }
             }
-            v = (qnr + xn[j]) - 2.f * v;
-        }
-        if (j == self) v = -INFINITY;
-        const uint64_t key = ((uint64_t)(MODE == 1 ? ~desc_key(v) : desc_key(v)) << 32) | (uint32_t)j;
-        if (key < worst) {
-            int p = filled < k ? filled : k - 1;
-            while (p > 0 && col[(p - 1) * 64] > key) { col[p * 64] = col[(p - 1) * 64]; --p; }
-            col[p * 64] = key;
-            if (filled < k) ++filled;
-            if (filled == k) worst = col[(k - 1) * 64];
-        }
-    }
-    int head = 0;
-    for (int r = 0; r < k; ++r) {
-        uint64_t mine = head < filled ? col[head * 64] : EMPTY_KEY;
-        uint64_t best = mine;
+        int head = 0;
+        for (int r = 0; r < kk; ++r) {
+            uint64_t mine = head < filled ? col[head * 64] : EMPTY_KEY;
+            uint64_t best = mine;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t lo = __shfl_xor((uint32_t)best, o, 64);
-            const uint32_t hi = __shfl_xor((uint32_t)(best >> 32), o, 64);
-            const uint64_t other = ((uint64_t)hi << 32) | lo;
-            best = other < best ? other : best;
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t lo = __shfl_xor((uint32_t)best, o, 64);
+                const uint32_t hi = __shfl_xor((uint32_t)(best >> 32), o, 64);
+                const uint64_t other = ((uint64_t)hi << 32) | lo;
+                best = other < best ? other : best;
+            }
+            if (mine == best && best != EMPTY_KEY) ++head;      // keys are unique (id in the low word)
+            if (best != EMPTY_KEY) after = best; else dry = true;   // nothing left: the remaining slots are padding
+            if (lane == 0) {
+                const uint32_t kb = (uint32_t)(best >> 32);
+                vals[row * k + base + r] = best != EMPTY_KEY ? key_value(MODE == 1 ? ~kb : kb) : (MODE == 1 ? 3.4028234663852886e38f : -INFINITY);
+                ids[row * k + base + r] = best != EMPTY_KEY ? (int64_t)(uint32_t)best : -1;
+            }
         }
-        if (mine == best && best != EMPTY_KEY) ++head;      // keys are unique (id in the low word)
-        if (lane == 0) {
-            const uint32_t kk = (uint32_t)(best >> 32);
-            vals[row * k + r] = best != EMPTY_KEY ? key_value(MODE == 1 ? ~kk : kk) : (MODE == 1 ? 3.4028234663852886e38f : -INFINITY);
-            ids[row * k + r] = best != EMPTY_KEY ? (int64_t)(uint32_t)best : -1;
-        }
+        first = false;
     }
 }
 
@@ -102,6 +113,8 @@ __global__ void row_sqnorm_kernel(const float *__restrict__ x, int64_t n, int D,
         if (lane == 0) out[i] = ss;
     }
 }
+
+constexpr int TOPK_SWEEP = 32;     // keys per lane and sweep: 4 waves x 32 x 64 lanes x 8 B = 64 KiB of LDS
 
 int64_t chunk_rows(int64_t nq, int64_t N) {
     int64_t c = ((int64_t)1 << 28) / (N > 0 ? N : 1);
@@ -120,7 +133,7 @@ extern "C" size_t ps_dot_topk_workspace_bytes(int64_t nq, int64_t N, int D, int 
 extern "C" int ps_dot_topk(const float *E, int64_t N, int D, const int64_t *qidx, int64_t nq, int k, int exclude_self,
                            float *vals, int64_t *ids, void *workspace, size_t workspace_bytes, ps_stream_t stream) {
     if (N < 0 || D <= 0 || nq < 0 || k <= 0) return PS_EINVAL;
-    if (k > 160 || N >= ((int64_t)1 << 32)) return PS_EUNSUPPORTED;
+    if (N >= ((int64_t)1 << 32)) return PS_EUNSUPPORTED;
     if (nq == 0) return PS_OK;
     if (!E || !qidx || !vals || !ids || !workspace) return PS_EINVAL;
     if (workspace_bytes < ps_dot_topk_workspace_bytes(nq, N, D, k)) return PS_EWORKSPACE;
@@ -129,7 +142,8 @@ extern "C" int ps_dot_topk(const float *E, int64_t N, int D, const int64_t *qidx
     char *base = reinterpret_cast<char *>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
     float *sims = reinterpret_cast<float *>(base);
     float *Q = reinterpret_cast<float *>(base + ((size_t)c * N * sizeof(float) + 255) / 256 * 256);
-    const size_t lds = (size_t)4 * k * 64 * sizeof(uint64_t);
+    const int kcap = k < TOPK_SWEEP ? k : TOPK_SWEEP;
+    const size_t lds = (size_t)4 * kcap * 64 * sizeof(uint64_t);
     for (int64_t q0 = 0; q0 < nq; q0 += c) {
         const int64_t rows = (nq - q0) < c ? (nq - q0) : c;
         int64_t g = ps_cdiv(rows * D, 256);
@@ -139,7 +153,7 @@ extern "C" int ps_dot_topk(const float *E, int64_t N, int D, const int64_t *qidx
         const int rc = ps_linear(Q, rows, D, E, D, nullptr, (int)N, nullptr, 0, nullptr, 0, 0, sims, stream);
         if (rc != PS_OK) return rc;
         hipLaunchKernelGGL(row_topk_kernel<0>, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), lds, st, sims, N, rows,
-                           qidx + q0, exclude_self, k, (const float *)nullptr, (const float *)nullptr,
+                           qidx + q0, exclude_self, k, kcap, (const float *)nullptr, (const float *)nullptr,
                            (const int32_t *)nullptr, (const uint32_t *)nullptr, 0, vals + q0 * k, ids + q0 * k);
         PS_CHECK_LAUNCH();
     }
@@ -156,7 +170,7 @@ extern "C" int ps_l2_topk(const float *X, int64_t N, int D, const float *Q, int6
                           const uint32_t *probe, int words, float *dist, int64_t *ids, void *workspace,
                           size_t workspace_bytes, ps_stream_t stream) {
     if (N < 0 || D <= 0 || nq < 0 || k <= 0) return PS_EINVAL;
-    if (k > 160 || N >= ((int64_t)1 << 32)) return PS_EUNSUPPORTED;
+    if (N >= ((int64_t)1 << 32)) return PS_EUNSUPPORTED;
     if (nq == 0) return PS_OK;
     if (!X || !Q || !dist || !ids || !workspace) return PS_EINVAL;
     if ((assign == nullptr) != (probe == nullptr) || (probe && words <= 0)) return PS_EINVAL;
@@ -175,13 +189,14 @@ extern "C" int ps_l2_topk(const float *X, int64_t N, int D, const float *Q, int6
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)g), dim3(256), 0, st, Q, nq, D, qn);
     PS_CHECK_LAUNCH();
-    const size_t lds = (size_t)4 * k * 64 * sizeof(uint64_t);
+    const int kcap = k < TOPK_SWEEP ? k : TOPK_SWEEP;
+    const size_t lds = (size_t)4 * kcap * 64 * sizeof(uint64_t);
     for (int64_t q0 = 0; q0 < nq; q0 += c) {
         const int64_t rows = (nq - q0) < c ? (nq - q0) : c;
         const int rc = ps_linear(Q + q0 * D, rows, D, X, D, nullptr, (int)N, nullptr, 0, nullptr, 0, 0, sims, stream);
         if (rc != PS_OK) return rc;
         hipLaunchKernelGGL(row_topk_kernel<1>, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), lds, st, sims, N, rows,
-                           (const int64_t *)nullptr, 0, k, qn + q0, xn, assign, probe ? probe + q0 * words : nullptr, words,
+                           (const int64_t *)nullptr, 0, k, kcap, qn + q0, xn, assign, probe ? probe + q0 * words : nullptr, words,
                            dist + q0 * k, ids + q0 * k);
         PS_CHECK_LAUNCH();
     }
