@@ -304,6 +304,18 @@ __device__ __forceinline__ void search_init(const int32_t *guide, const unsigned
     }
 }
 
+#ifndef PS_WS_DEBUG
+#define PS_WS_DEBUG 0      // knock-outs (tools/ws_knockout.sh; wrong results): 1 step 0 without its search, 2 walks stop after step 0,
+#endif                     // 4 no count / select phases, 8 no uniforms (constant 0.5)
+#if PS_WS_DEBUG & 16      // timeline (tools/ws_trace.py): s_memtime at the phase boundaries of the first 16384 start nodes
+__device__ unsigned long long ps_ws_trace_buf[16384 * 12];
+#define PS_WS_STAMP(slot) do { if (lane == 0 && i < 16384) ps_ws_trace_buf[i * 12 + (slot)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int ps_debug_ws_trace(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ps_ws_trace_buf), sizeof(unsigned long long) * 16384 * 12);
+}
+#else
+#define PS_WS_STAMP(slot) do {} while (0)
+#endif
 constexpr int WAVES_PER_BLOCK = 1;   // one start node per workgroup: the dispatcher load-balances uneven nodes
 constexpr int BITMAP_WORDS = 40;   // counts <= 1024 -> 33 words, padded
 
@@ -339,6 +351,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             }
             continue;
         }
+        PS_WS_STAMP(0);
         const bool stream = a.rng_mode != PS_RNG_PHILOX, raw = a.rng_mode == PS_RNG_STREAM_RAW;
         const int64_t ubase0 = stream ? uniform_i64(a.uoff[i]) : 0;
 
@@ -354,6 +367,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         }
         const LdsEdges lrow{reinterpret_cast<const unsigned char *>(hkey), b0};
         ps_wave_lds_sync();
+        PS_WS_STAMP(1);
         // two walks per lane (w and w + 64) advance in lockstep: their CDF probes are independent, so
         // every iteration of the search loop keeps two loads in flight per lane.
         for (int rd = 0; rd < R; ++rd) {
@@ -386,17 +400,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                     uB = uB1;
                 }
                 int32_t nA = -1, nB = -1;
-                if (staged && st == 0) search_two(lrow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
+                if (PS_WS_DEBUG & 8) { uA = 0.5; uB = 0.25; }
+                if ((PS_WS_DEBUG & 2) && st > 0) { aliveA = false; aliveB = false; }
+                if ((PS_WS_DEBUG & 1) && st == 0) { nA = grow.k(lo0 + (eidx_t)((uint32_t)lane % (uint32_t)(hi0 - lo0))); nB = nA; }
+                else if (staged && st == 0) search_two(lrow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
                 else if (a.buckets) search_two_buckets(a.buckets, grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
                 else search_two(grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
                 if (aliveA) curA = nA;
                 if (aliveB) curB = nB;
                 if (actA) posb[wA * a.L + st] = nA;
                 if (actB) posb[wB * a.L + st] = nB;
+                if (w0 == 0) PS_WS_STAMP(2 + rd * 2 + (st ? 1 : 0));
             }
         }
         }
-        for (int rd = 0; rd < R; ++rd) {
+        PS_WS_STAMP(6);
+        for (int rd = 0; rd < ((PS_WS_DEBUG & 4) ? 0 : R); ++rd) {
         const int32_t *posb = posb_all + rd * NP * 64;
         int32_t *oid = a.ids + ((int64_t)rd * a.B + i) * a.T;
         int32_t *ocn = a.counts + ((int64_t)rd * a.B + i) * a.T;
@@ -404,6 +423,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         for (int h = lane; h < HS; h += 64) { hkey[h] = -1; hcnt[h] = 0; hfirst[h] = 0x7fffffff; }
         for (int b = lane; b < nbw; b += 64) bitmap[b] = 0u;
         ps_wave_lds_sync();
+        // (inserting the NP positions of a lane together -- all pending compare-and-swaps of a probing round in flight, then the
+        // count / first-visit atomics in one batch -- measured 2-4 x SLOWER for this phase: 22 K / 37 K cycles against 9.9 K)
         int32_t vid[NP], slot[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -433,6 +454,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             }
         }
         ps_wave_lds_sync();
+        PS_WS_STAMP(7 + rd * 2);
         // ---------------- select phase ------------------------------------------------
         int emitted = 0;
         for (int wd = nbw - 1; wd >= 0 && emitted < a.T; --wd) {
@@ -457,6 +479,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         for (int t = nv + lane; t < a.T; t += 64) { oid[t] = -1; ocn[t] = 0; }
         if (lane == 0) a.nvalid[(int64_t)rd * a.B + i] = nv;
         ps_wave_lds_sync();
+        PS_WS_STAMP(8 + rd * 2);
         }
     }
 }
