@@ -11,19 +11,24 @@ def sync_time(fn):
     torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return r, time.perf_counter() - t
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--frac", type=float, default=0.25); a = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument("--frac", type=float, default=0.25)
+    ap.add_argument("--shard", type=int, default=1, help="sample / encode / search only the first 1/shard of the items (one rank of a "
+                    "sharded job: the graph is replicated, the items are not)")
+    a = ap.parse_args()
     from pinsage_hip import synth, sampling, dense
     from pinsage_hip.graph import DeviceGraph
     from utils.random_walk import RandomWalkSampler
     from model.pinsage import PinSage
     dev = torch.device("cuda")
     M, U, R = int(100e6 * a.frac), int(10e6 * a.frac), int(1e9 * a.frac)
-    print(f"frac {a.frac}: M={M} U={U} R={R} (directed edges {2*R})", flush=True)
+    print(f"frac {a.frac}: M={M} U={U} R={R} (directed edges {2*R}), item shard 1/{a.shard}", flush=True)
     (ei, ew), t = sync_time(lambda: synth.bipartite_ratings(U, M, R, device=dev)); print(f"synthetic ratings: {t:.2f}s", flush=True)
     g, t = sync_time(lambda: DeviceGraph(ei, ew)); del ei, ew; torch.cuda.empty_cache()
     print(f"DeviceGraph build: {t:.2f}s  V={g.V} E={g.E} maxdeg={g.max_degree} resident {g.nbytes()/1e9:.1f} GB; "
           f"GPU mem in use {torch.cuda.memory_allocated()/1e9:.1f} GB", flush=True)
     smp = RandomWalkSampler.from_graph(g, 2, 100, rng="philox", seed=42)
+    M_all = M
+    M = M // a.shard                                        # this rank's items
     nodes = torch.arange(M, device=dev)
     batches = []
     for layer in range(2):
