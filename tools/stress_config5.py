@@ -52,10 +52,17 @@ def main():
         e = torch.nn.functional.normalize(torch.randn(min(4_000_000, M - s), 256, device=dev), dim=1)
         codes[s:s + e.size(0)] = dense.lsh_encode(e, A)
     torch.cuda.synchronize(); print(f"LSH encode of {M} items incl. generating inputs: {time.perf_counter()-t0:.2f}s", flush=True)
+    planes, t = sync_time(lambda: dense.lsh_expand(codes))
+    print(f"fp4 sign planes of {M} codes: {t*1e3:.1f} ms, {planes.numel()/1e9:.1f} GB", flush=True)
     for nq in (1024, 16384):
-        (d, i), t = sync_time(lambda: dense.hamming_topk(codes[:nq], codes, 11))
+        (dm, im), t = sync_time(lambda: dense.hamming_topk(codes[:nq], codes, 11, planes=planes))
+        (dm, im), t = sync_time(lambda: dense.hamming_topk(codes[:nq], codes, 11, planes=planes))
+        print(f"top-11 of {nq} queries over {M} codes, fp4-MFMA scan: {t*1e3:.1f} ms -> {nq/t/1e3:.1f} K queries/s, "
+              f"{nq*M*512/t/1e15:.2f} P sign-ops/s", flush=True)
+        (d, i), t = sync_time(lambda: dense.hamming_topk(codes[:nq], codes, 11, use_mfma=False))
+        assert torch.equal(dm, d) and torch.equal(im, i)      # the two scans agree bit for bit at this size too
         assert bool((i[:, 0] == torch.arange(nq, device=dev)).all())
-        print(f"top-11 of {nq} queries over {M} codes (1.6 GB x frac table): {t*1e3:.1f} ms -> {nq/t/1e3:.1f} K queries/s, "
+        print(f"top-11 of {nq} queries over {M} codes, popcount scan: {t*1e3:.1f} ms -> {nq/t/1e3:.1f} K queries/s, "
               f"{nq*M*64/t/1e12:.1f} TB/s logical", flush=True)
     print(f"peak GPU memory {torch.cuda.max_memory_allocated()/1e9:.1f} GB", flush=True)
 
