@@ -28,7 +28,9 @@
 //             to a lane-private LDS column (no cross-lane traffic, no atomics); a column that fills up is compacted to
 //             its k best and the lane's threshold tightened (exact: ids ascend during the sweep).
 //   merge   : every slice leaves one sorted k-list per query (the two lanes of a query merge theirs in LDS);
-//             slice_merge_kernel merges them by (distance, row): 16 lanes per query, k rounds of a DPP row minimum.
+//             slice_merge_kernel merges them by (distance, row): 16 lanes per query, k rounds of a DPP row minimum
+//             (slice_merge64_kernel, one wave per query, when few queries over a large table are cut into 17..64 slices:
+//             1 024 queries x 10^6 codes 1.53 -> 0.42 ms, 64 x 59 047 0.129 -> 0.067 ms; tools/hamming_crossover.py).
 // One workgroup = 8 waves = 256 queries x one slice of the table; item tiles are shared through a 3-deep LDS ring
 // (counted vmcnt, raw s_barrier); waves 4-7 run their tile epilogue one tile late so that the two waves of a SIMD
 // alternate between the matrix pipe and the VALU instead of meeting at both.
@@ -403,6 +405,48 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t *__restr
     }
 }
 
+// the same merge for up to 64 lists (few queries over a large table are cut into more slices, so that they still fill the
+// chip): one wave per query, lane j = the head of list j, wave minimum by DPP + v_readlane
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#define PS_STEP(ctrl, rows)                                                                                     \
+    {                                                                                                           \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)v, ctrl, rows, 0xf, false); \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(v >> 32), ctrl, rows, 0xf, false); \
+        const uint64_t o = ((uint64_t)hi << 32) | lo;                                                           \
+        v = o < v ? o : v;                                                                                      \
+    }
+    PS_STEP(0xB1, 0xf) PS_STEP(0x4E, 0xf) PS_STEP(0x141, 0xf) PS_STEP(0x140, 0xf) PS_STEP(0x142, 0xa) PS_STEP(0x143, 0xc)
+#undef PS_STEP
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+__global__ __launch_bounds__(256) void slice_merge64_kernel(const int32_t *__restrict__ din, const int32_t *__restrict__ rin,
+                                                            int P, int64_t nq, int k, int64_t id_offset,
+                                                            int32_t *__restrict__ dout, int64_t *__restrict__ iout) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (q >= nq) return;
+    const bool mine = lane < P;
+    const int64_t base = mine ? ((int64_t)lane * nq + q) * k : 0;
+    constexpr uint64_t NONE = ~0ull;
+    auto head = [&](int ptr) -> uint64_t {
+        if (!mine || ptr >= k) return NONE;
+        const int32_t r = rin[base + ptr];
+        return r < 0 ? NONE : ((uint64_t)(uint32_t)din[base + ptr] << 32) | (uint32_t)r;
+    };
+    int ptr = 0;
+    uint64_t key = head(0);
+    for (int r = 0; r < k; ++r) {
+        const uint64_t m = wave_min_u64(key);
+        if (lane == 0) {
+            dout[q * k + r] = m == NONE ? 0x7fffffff : (int32_t)(m >> 32);
+            iout[q * k + r] = m == NONE ? -1 : (int64_t)(uint32_t)m + id_offset;
+        }
+        if (key == m && m != NONE) key = head(++ptr);
+    }
+}
+
 // one wave per query: thr0 = the k-th smallest of the query's group minima (all bound lists), or nbits (admit
 // everything) when the sample held fewer than k groups
 __global__ __launch_bounds__(256) void bound_select_kernel(const int32_t *__restrict__ bl, int64_t nq, int nvals, int k,
@@ -411,9 +455,9 @@ __global__ __launch_bounds__(256) void bound_select_kernel(const int32_t *__rest
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t q = wave; q < nq; q += nw) {
-        int v[8];
+        int v[16];                                           // nvals <= 1024 (make_plan)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 16; ++r) {
             const int c = r * 64 + lane;
             v[r] = c < nvals ? bl[q * nvals + c] : 0x7fffffff;
         }
@@ -422,7 +466,7 @@ __global__ __launch_bounds__(256) void bound_select_kernel(const int32_t *__rest
             const int mid = (lo + hi) >> 1;
             int c = 0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) c += __popcll(__ballot(v[r] <= mid));
+            for (int r = 0; r < 16; ++r) c += __popcll(__ballot(v[r] <= mid));
             if (c >= k) hi = mid; else lo = mid + 1;
         }
         if (lane == 0) thr0[q] = lo;
@@ -464,13 +508,13 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     const int slots = env_int("PS_HAMMING_MFMA_SLOTS", 256);      // one 8-wave workgroup per CU
     int64_t s = slots / p.nqb;
     if (s < 1) s = 1;
-    if (s > 16) s = 16;
+    if (s > 64) s = 64;                                    // merge fan-in: 16 lanes per query up to 16 lists, a wave beyond
     while (s > 1 && p.tiles / s < 32) --s;                 // a slice is at least 32 tiles (1024 items)
     const int64_t cap_tiles = ((int64_t)1 << p.shift) >> 5;
     if (p.tiles > s * cap_tiles) s = (p.tiles + cap_tiles - 1) / cap_tiles;   // slice-local ids must fit under the distance bits
     p.tiles_per_slice = ((p.tiles + s - 1) / s + IT - 1) / IT * IT;
     p.slices = (int)((p.tiles + p.tiles_per_slice - 1) / p.tiles_per_slice);
-    if (p.slices > 16) return p;                           // merge fan-in: one list per slice, 16 lanes per query
+    if (p.slices > 64) return p;                           // merge fan-in: one list per slice, one lane per list
     // bound pass: 1/5 of the table (measured on MI355X, 10 000 x 59 047 x 512 bit: 5 % 0.67 ms, 10 % 0.48, 20 % 0.44,
     // 30 % 0.45: every candidate that passes the bound costs ~180 SIMD cycles in the collect pass), at least 16 groups
     // per lane so that a lane's list can hold KM real minima
@@ -480,7 +524,7 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     if (st > p.tiles) st = p.tiles;
     int64_t bs = slots / p.nqb;
     if (bs < 1) bs = 1;
-    if (bs > 8) bs = 8;                                    // <= 16 lists of KM <= 32 values per query (bound_select: 512)
+    if (bs > 512 / p.km) bs = 512 / p.km;                  // <= 2 bs lists of KM values per query (bound_select: 1024)
     while (bs > 1 && st / bs < 16) --bs;
     p.btiles_per_slice = ((st + bs - 1) / bs + IT - 1) / IT * IT;
     p.bslices = (int)((st + p.btiles_per_slice - 1) / p.btiles_per_slice);
@@ -597,8 +641,12 @@ extern "C" int ps_hamming_topk_mfma(const void *qplanes, int64_t nq, const void 
         default: return PS_EUNSUPPORTED;
     }
     if (rc != PS_OK) return rc;
-    hipLaunchKernelGGL(slice_merge_kernel, dim3((unsigned)ps_cdiv(nq, 16)), dim3(256), 0, st, cd, cr, p.slices, nq, k, id_offset,
-                       dist, ids);
+    if (p.slices <= 16)
+        hipLaunchKernelGGL(slice_merge_kernel, dim3((unsigned)ps_cdiv(nq, 16)), dim3(256), 0, st, cd, cr, p.slices, nq, k, id_offset,
+                           dist, ids);
+    else
+        hipLaunchKernelGGL(slice_merge64_kernel, dim3((unsigned)ps_cdiv(nq, 4)), dim3(256), 0, st, cd, cr, p.slices, nq, k, id_offset,
+                           dist, ids);
     PS_CHECK_LAUNCH();
     return PS_OK;
 }

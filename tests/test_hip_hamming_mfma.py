@@ -5,7 +5,7 @@ restatement of faiss' hammings_knn_hc (reference utils/nearest_neighbors.py:47-6
 Edge cases the domain has: a ragged last tile (N % 32 != 0), nq % 32 != 0 and nq % 256 != 0, exact duplicates
 (distance ties broken by id), a table of identical codes (EVERY distance ties: the lane-private candidate columns
 overflow and are compacted over and over), clustered codes, k = 1 / 16 / 17 / 32 (both column capacities), every
-served code size, id offsets (shards)."""
+served code size, id offsets (shards), 4 to 64 table slices per query block (both merge kernels)."""
 import numpy as np
 import pytest
 import torch
@@ -58,6 +58,8 @@ def test_sign_planes_layout():
     (4, "random", 4200, 96, 5),
     (64, "same", 4100, 70, 11),
     (32, "same", 5000, 64, 20),
+    (64, "clustered", 40000, 100, 11),      # few queries, larger table: 39 slices -> the wave-per-query merge
+    (16, "random", 70001, 64, 7),           # 64 slices
 ])
 def test_mfma_scan_matches_oracle_and_popcount(cs, kind, N, nq, k):
     from oracle import c_oracle as co
