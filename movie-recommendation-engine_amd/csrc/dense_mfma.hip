@@ -18,8 +18,11 @@
 // fetches its four k values of one group (k = 8g + 2t + h, t = 0..3) with a single ds_read_b128;
 // row stride BK+4 floats keeps the b128 reads bank-conflict free.  The k-permutation is done
 // in registers while staging (two float4 global loads per row-group), global loads for the next
-// K step are in flight while the current one is multiplied, and inside a K step the LDS fragments of
-// k-group g+1 are requested before the 16 MFMAs of group g (order pinned with sched_group_barrier).
+// K step are in flight while the current one is multiplied -- issued one after every four MFMAs, not in a burst --
+// and inside a K step the LDS fragments of k-group g+1 are requested before the 16 MFMAs of group g (order
+// pinned with sched_group_barrier).  Two blocks per CU (launch bound): the older wave of a SIMD owns the MFMA pipe and
+// the younger runs in its gaps; MFMA and VALU instructions do not overlap on a SIMD, which is what prices the epilogue
+// (tools/gemm_trace.py).
 #include "ps_common.h"
 
 #ifndef PS_GEMM_DEBUG
