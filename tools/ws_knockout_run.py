@@ -19,4 +19,12 @@ def timed(fn, reps=10):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps
 ph = timed(lambda: sampling.walk_sample_layers(g, range(0, M), 10, 2, 100, 2, rng="philox", seed=1, call=0))
-print(f"{os.environ.get('PS_HIP_LIB', 'base').split('/')[-1]}: philox {ph:.4f} ms", flush=True)
+# numpy-stream mode with the uniforms already generated: the walk kernel alone
+np.random.seed(1)
+raw = dense.mt19937_random_sample(2 * M * 200, dev, advance=False)      # doubles: PS_RNG_STREAM
+torch.cuda.synchronize()
+try:
+    st = timed(lambda: sampling.walk_sample_layers(g, range(0, M), 10, 2, 100, 2, rng="numpy", uniforms=raw))
+except Exception as ex:
+    st = float("nan"); print("stream mode probe failed:", ex)
+print(f"{os.environ.get('PS_HIP_LIB', 'base').split('/')[-1]}: philox {ph:.4f} ms, uniform stream {st:.4f} ms", flush=True)
