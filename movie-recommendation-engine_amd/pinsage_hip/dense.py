@@ -79,7 +79,7 @@ def lsh_encode(x, A):
     return codes
 
 
-HAMMING_MAX_K = 64        # ps_hamming_topk (popcount scan); the MFMA scan serves k <= 32 and falls back above
+HAMMING_MAX_K = 64        # ps_hamming_topk (popcount scan); the MFMA scan serves k <= 32; beyond 64: _hamming_topk_large_k
 
 
 def lsh_expand(codes):
@@ -112,8 +112,7 @@ def hamming_topk(qcodes, codes, k, id_offset=0, planes=None, use_mfma=True):
     nq, cs = int(qcodes.size(0)), int(qcodes.size(1))
     N = int(codes.size(0))
     if k > HAMMING_MAX_K:
-        raise ValueError(f"LSH search supports k <= {HAMMING_MAX_K} (a query's k best keys live across the 64 lanes of a "
-                         f"wave); got k = {k}.  faiss accepts any k: split the request or use the exact search")
+        return _hamming_topk_large_k(qcodes, codes, k, id_offset)
     dist = torch.empty((nq, k), dtype=torch.int32, device=qcodes.device)
     ids = torch.empty((nq, k), dtype=torch.int64, device=qcodes.device)
     L = nv.lib()
@@ -133,6 +132,33 @@ def hamming_topk(qcodes, codes, k, id_offset=0, planes=None, use_mfma=True):
         nv.call("ps_hamming_topk", nv.ptr(qcodes), nv.i64(nq), nv.ptr(codes) if N else nv.C.c_void_p(0), nv.i64(N),
                                    nv.i32(cs), nv.i32(k), nv.i64(id_offset), nv.ptr(dist), nv.ptr(ids), nv.ptr(ws),
                                    nv.C.c_size_t(wsb), nv.stream())
+    return dist, ids
+
+
+LARGE_K_SIGN_BYTES = 8 << 30      # budget for the +-1 float image of the code table in the k > 64 path
+
+
+def _signs(codes):
+    """uint8 [n, cs] -> float32 [n, 8 cs] of +-1 (any fixed bit order: both operands use the same)"""
+    shifts = torch.arange(8, device=codes.device, dtype=torch.uint8)
+    bits = (codes.unsqueeze(-1) >> shifts) & 1
+    return bits.reshape(codes.size(0), -1).to(torch.float32) * 2.0 - 1.0
+
+
+def _hamming_topk_large_k(qcodes, codes, k, id_offset):
+    """k > 64 (faiss.IndexLSH.search accepts any k): between +-1 vectors the squared L2 distance is 4 x the Hamming distance
+    -- small integers, exact in fp32 -- so the exact L2 search (ps_l2_topk: fp32-MFMA GEMM + multi-sweep row top-k, any k,
+    ties by id) returns the same (distance, id) order as the scans.  Costs a float image of the table (2 KiB per 512-bit
+    code): meant for the occasional large request, not for the hot path."""
+    N, nbits = int(codes.size(0)), int(codes.size(1)) * 8
+    if N * nbits * 4 > LARGE_K_SIGN_BYTES:
+        raise ValueError(f"LSH search with k = {k} > {HAMMING_MAX_K} expands the code table to floats "
+                         f"({N * nbits * 4 / 2 ** 30:.1f} GiB here, limit {LARGE_K_SIGN_BYTES >> 30} GiB): split the table or the request")
+    d2, ids = l2_topk(_signs(codes), _signs(qcodes), k)
+    missing = ids < 0
+    dist = torch.where(missing, torch.full_like(d2, 0.0), d2 * 0.25).round().to(torch.int32)
+    dist[missing] = 0x7fffffff
+    ids = torch.where(missing, ids, ids + int(id_offset))
     return dist, ids
 
 

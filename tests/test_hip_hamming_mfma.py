@@ -157,3 +157,24 @@ def test_mfma_scan_random_shapes_equal_popcount():
         dm, im = dense.hamming_topk(qt, ct, k, id_offset=off, planes=dense.lsh_expand(ct))
         dv, iv = dense.hamming_topk(qt, ct, k, id_offset=off, use_mfma=False)
         assert torch.equal(dm, dv) and torch.equal(im, iv), (nq, N, cs, k, few)
+
+
+@pytest.mark.parametrize("k", [65, 100, 500])
+def test_lsh_search_any_k(k):
+    """faiss.IndexLSH.search takes any k; beyond the scans' 64 the request runs as an exact L2 search over +-1 vectors
+    (squared distance = 4 x Hamming): same (distance, id) order as the C oracle, padding (INT32_MAX, -1) past the table."""
+    from oracle import c_oracle as co
+    from pinsage_hip import dense
+    rs = np.random.RandomState(k)
+    N, cs, nq = 400, 32, 19
+    codes = _codes(rs, N, cs, "clustered")
+    codes[50] = codes[3]; codes[399] = codes[3]
+    q = codes[rs.permutation(N)[:nq]].copy()
+    q[0] = codes[3]
+    d, i = dense.hamming_topk(torch.from_numpy(q).cuda(), torch.from_numpy(codes).cuda(), k, id_offset=1000)
+    d, i = d.cpu().numpy(), i.cpu().numpy()
+    kk = min(k, N)
+    rd, ri = co.hamming_topk(q, codes, kk, threads=4)
+    assert np.array_equal(i[:, :kk], ri + 1000) and np.array_equal(d[:, :kk].astype(np.float32), rd)
+    if k > N:
+        assert np.all(i[:, N:] == -1) and np.all(d[:, N:] == 0x7fffffff)

@@ -234,8 +234,8 @@ def test_error_paths_raise_loudly():
     idx.build(torch.randn(10, 16))
     with pytest.raises(AssertionError):
         idx.search(torch.randn(2, 15), 3)                           # wrong dimensionality
-    with pytest.raises(ValueError, match="k <= 64"):
-        idx.search(torch.randn(2, 16), 100)                         # k > 64: the limit is named
+    d, i = idx.search(torch.randn(2, 16), 100)                      # k > 64 and > ntotal: served (exact path), padded like faiss
+    assert d.shape == (2, 100) and np.all(i[:, 10:] == -1) and np.all(i[:, :10] >= 0)
 
 
 def test_hard_negatives_match_reference_semantics():
