@@ -39,16 +39,26 @@ MFMA_FP4_PEAK = 1024 * 131072 / 32 * 2.4e9
 # v_bcnt per 32-bit word and 64 pairs = 256 B of logical code bytes per 4 clocks per SIMD
 VALU_POPCNT_PEAK = 1024 * 256 / 4 * 2.4e9
 
+# Indexed 1 KiB-row gathers served on-die (MI355X_MICROARCH.md, "Indexed rows"): rows every workgroup shares (an XCD's L2)
+# 16.8-18.8 TB/s chip-wide, uniformly random rows of a 38 MB Infinity-Cache-resident table 8.6 TB/s.  The pooled hidden rows
+# (M x H x 4 = 60 MB at ML-25M) are a popularity-skewed mix of both, so the upper figure is the bound when the table fits.
+MALL_BYTES = 256 << 20
+ONDIE_GATHER_PEAK = 18.8e12
+
 # BASELINE.json configs that fit one GPU (configs[1], configs[2]); the default run is the configuration the metric is
-# quoted on (d = 256, T = 10, 512-bit codes)
-PRESETS = {2: dict(dim=128, T=10, lsh_bits=256), 3: dict(dim=256, T=50, lsh_bits=512)}
+# quoted on (d = 256, T = 10, 512-bit codes).  5 = configs[4] (100 M items / 10^9 ratings, d = 256, T = 10, 8 GPUs) as ONE of
+# its eight ranks sees it: the whole graph (2 x 10^9 directed edges) replicated in HBM, one item shard of 12.5 M, Philox
+# uniforms; the gathers of the other seven ranks' rows are stood in for by local buffers of the gathered shape.
+PRESETS = {2: dict(dim=128, T=10, lsh_bits=256), 3: dict(dim=256, T=50, lsh_bits=512),
+           5: dict(dim=256, T=10, lsh_bits=512, rng="philox")}
+CONFIG5 = dict(num_users=10_000_000, num_items=100_000_000, num_ratings=1_000_000_000, ranks=8)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=0, help="default 50 (config 5: 5)")
+    ap.add_argument("--warmup", type=int, default=-1, help="default 5 (config 5: 1)")
     ap.add_argument("--dim", type=int, default=256, help="embedding dim d (BASELINE metric: d=256)")
     ap.add_argument("--T", type=int, default=10, help="neighbours kept per node (north_star: T=10)")
     ap.add_argument("--lsh-bits", type=int, default=0, help="default 2*dim (256-bit @128, 512-bit @256)")
@@ -58,14 +68,19 @@ def parse():
     ap.add_argument("--rng", default="numpy", choices=["philox", "numpy"],
                     help="numpy = the reference's global np.random MT19937 stream (bit-exact ids; the mode the goldens pin); "
                          "philox = counter-based, shard-count invariant, no stream generation")
-    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3],
-                    help="BASELINE.json config preset: 2 = d128/T10/256-bit, 3 = d256/T50/512-bit (the rocprof roofline run)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 5],
+                    help="BASELINE.json config preset: 2 = d128/T10/256-bit, 3 = d256/T50/512-bit (the rocprof roofline run), "
+                         "5 = one rank's shard of the 100 M-item / 10^9-rating stress graph (HBM-bound sampler)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="start items timed on the CPU (0 = the whole catalogue)")
     a = ap.parse_args()
     if a.config:
         for k, v in PRESETS[a.config].items():
             setattr(a, k, v)
+    if a.steps <= 0:
+        a.steps = 5 if a.config == 5 else 50
+    if a.warmup < 0:
+        a.warmup = 1 if a.config == 5 else 5
     return a
 
 
@@ -73,29 +88,34 @@ def ceil_log2p1(d):
     return torch.ceil(torch.log2((d + 1).double())).long()
 
 
-def sampler_algorithmic_bytes(graph, sampler, nodes, T, W, L, call, stream_mode):
-    """per taken step from v: 16 B (int64 rowptr pair) + 8 B * ceil(log2(deg v + 1)) (fp64
-    CDF probes of the binary search) + 4 B (col) [+ 8 B uniform in stream mode]; per start node
-    T * 8 B + 4 B of output.  The walks are replayed exactly with ps_walk_paths (same Philox counters)."""
+def sampler_algorithmic_bytes(graph, sampler, nodes, T, W, L, call, stream_mode, chunk=1 << 20):
+    """per taken step from v: 8 B (the node's row bounds: two 32-bit offsets -- the kernel reads ONE 8-byte
+    (row start, degree) record, csrc/walk_sample.hip load_row; edge ids are uint32, E < 2^32 is enforced by ps_csr_build)
+    + 8 B * ceil(log2(deg v + 1)) (fp64 CDF probes of the binary search) + 4 B (col) [+ 8 B uniform in stream mode];
+    per start node T * 8 B + 4 B of output.  The walks are replayed exactly with ps_walk_paths (same Philox counters),
+    `chunk` start nodes at a time."""
     from pinsage_hip import sampling
     deg = graph.rowptr[1:] - graph.rowptr[:-1]
-    B = nodes.numel()
-    per_step_fixed = 16 + 4 + (8 if stream_mode else 0)
-    d0 = deg[nodes]
-    act = d0 > 0
-    steps = int(act.sum().item()) * W
-    nbytes = int(((ceil_log2p1(d0) * 8 + per_step_fixed) * act).sum().item()) * W
-    if L > 1:
-        starts = nodes.repeat_interleave(W)
-        paths = sampling.walk_paths(graph, starts, L, rng="philox", seed=sampler.seed, call=call, walk_mod=W)
-        for st in range(1, L):
-            src = paths[:, st - 1].long()
-            ok = src >= 0
-            d = deg[src.clamp(min=0)] * ok
-            took = d > 0
-            steps += int(took.sum().item())
-            nbytes += int(((ceil_log2p1(d) * 8 + per_step_fixed) * took).sum().item())
-    nbytes += B * (T * 8 + 4)
+    per_step_fixed = 8 + 4 + (8 if stream_mode else 0)
+    steps, nbytes = 0, 0
+    for c0 in range(0, nodes.numel(), chunk):
+        nd = nodes[c0:c0 + chunk]
+        d0 = deg[nd]
+        act = d0 > 0
+        steps += int(act.sum().item()) * W
+        nbytes += int(((ceil_log2p1(d0) * 8 + per_step_fixed) * act).sum().item()) * W
+        if L > 1:
+            starts = nd.repeat_interleave(W)
+            paths = sampling.walk_paths(graph, starts, L, rng="philox", seed=sampler.seed, call=call, walk_mod=W)
+            for st in range(1, L):
+                src = paths[:, st - 1].long()
+                ok = src >= 0
+                d = deg[src.clamp(min=0)] * ok
+                took = d > 0
+                steps += int(took.sum().item())
+                nbytes += int(((ceil_log2p1(d) * 8 + per_step_fixed) * took).sum().item())
+            del starts, paths
+    nbytes += nodes.numel() * (T * 8 + 4)
     return nbytes, steps
 
 
@@ -126,8 +146,13 @@ def main():
     from utils.nearest_neighbors import lsh_rotation_matrix
     from model.pinsage import PinSage
 
-    U, M, R = [max(8, int(v * a.scale)) for v in
-               (synth.ML25M["num_users"], synth.ML25M["num_items"], synth.ML25M["num_ratings"])]
+    big = a.config == 5
+    if big:
+        assert world == 1, "--config 5 plays ONE rank of the 8-rank job on one GPU (the driver's N > 1 runs use the default config)"
+        src = {k: max(8, int(v * a.scale)) for k, v in CONFIG5.items() if k != "ranks"}
+    else:
+        src = {k: max(8, int(v * a.scale)) for k, v in synth.ML25M.items()}
+    U, M, R = src["num_users"], src["num_items"], src["num_ratings"]
     F_IN, HID, D, LAYERS, W, L, T = 128, 256, a.dim, 2, 100, 2, a.T
     nbits = a.lsh_bits or 2 * D
     ei, ew = synth.bipartite_ratings(U, M, R, seed=20240601, device=dev)
@@ -137,19 +162,29 @@ def main():
     del ei, ew
     torch.cuda.synchronize()
     t_graph = time.time() - t0
+    if big:
+        graph.wsorted = None                       # the sorted fp64 weights (16 GB here) are only kept for inspection
+        torch.cuda.empty_cache()
     sampler = RandomWalkSampler.from_graph(graph, walk_length=L, num_walks=W, rng=a.rng, seed=42)
     torch.manual_seed(2)
     model = PinSage(F_IN, HID, D, LAYERS).to(dev).eval()
     params = {k: v.detach().float().contiguous() for k, v in model.state_dict().items()}
-    gen = torch.Generator(device="cpu").manual_seed(1)
-    x_full = torch.randn(M, F_IN, generator=gen)
     A = torch.from_numpy(lsh_rotation_matrix(D, nbits)).to(dev)
-    pipe = ShardedPinSage(params, LAYERS, sampler, M)
-    x_loc = x_full[pipe.lo:pipe.hi].to(dev).contiguous()
-    x_rep = x_full.to(dev).contiguous() if world > 1 else None      # replicated features (30 MB): lets every rank
-    del x_full                                                       # recompute layer-0 rows instead of gathering them
-    nq_local = max(1, a.queries // world)
-    nq = nq_local * world
+    sim_ranks = CONFIG5["ranks"] if big else 1
+    pipe = ShardedPinSage(params, LAYERS, sampler, M, standin=(0, sim_ranks) if big else None)
+    if big:
+        x_loc = torch.randn(pipe.hi - pipe.lo, F_IN, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        x_rep = None                               # hidden rows are gathered (a replicated feature table would be 51 GB)
+    else:
+        gen = torch.Generator(device="cpu").manual_seed(1)
+        x_full = torch.randn(M, F_IN, generator=gen)
+        x_loc = x_full[pipe.lo:pipe.hi].to(dev).contiguous()
+        x_rep = x_full.to(dev).contiguous() if world > 1 else None      # replicated features (30 MB): lets every rank
+        del x_full                                                       # recompute layer-0 rows instead of gathering them
+    ranks_total = world * sim_ranks
+    nq_local = max(1, a.queries // ranks_total)
+    nq = nq_local * ranks_total
+    items_per_step = (pipe.hi - pipe.lo) if big else M              # config 5: this rank's shard is what a step processes
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     phase_ms = {"embed": 0.0, "index": 0.0, "query": 0.0}
@@ -226,7 +261,7 @@ def main():
         phase_ms["index"] += e1.elapsed_time(e2)
         phase_ms["query"] += e2.elapsed_time(e3)
     ms_per_step = elapsed / a.steps * 1e3
-    value = M * a.steps / elapsed
+    value = items_per_step * a.steps / elapsed
     ksum = timer.summary()
 
     out = None
@@ -240,7 +275,12 @@ def main():
         samp_bytes = (sb0 + sb1) / 2.0
         b0 = sampling.walk_sample(graph, nodes, T, W, L, rng="philox", seed=42, call=0)
         valid = ((b0.ids >= 0) & (b0.ids <= M - 1)).sum().item()
+        del b0
         pool_bytes = valid * HID * 4 + n_loc * HID * 4 + n_loc * T * 8
+        # where the gathered rows live decides the bound: a hidden-row table that fits the Infinity Cache (60 MB at ML-25M)
+        # is served on-die (L2 hits for popular rows, MALL for the rest); config 5's gathered table (102 GB) is HBM
+        pool_table = pipe.world * pipe.chunk * HID * 4 if pipe.world > 1 else M * HID * 4
+        pool_bound, pool_peak = ("mall", ONDIE_GATHER_PEAK) if pool_table <= MALL_BYTES else ("hbm", HBM_PEAK)
         # executed flops: lin_self is composed into lin_update once per forward (2 * H^3 + 2 * H^2 per layer),
         # so per item: input_proj + layers * (h W'^T + h_neigh Wu2^T) + output_proj
         lin_flops_step = 2.0 * n_loc * (F_IN * HID + LAYERS * (2 * HID * HID) + HID * D) + LAYERS * (2.0 * HID ** 3 + 2.0 * HID * HID)
@@ -259,7 +299,7 @@ def main():
         # the fused launch samples LAYERS rounds per start node: per-launch work = the sum over the layers
         add("ps_walk_sample_layers", "hbm", sb0 + sb1, HBM_PEAK)
         add("ps_walk_sample", "hbm", samp_bytes, HBM_PEAK)
-        add("ps_importance_pool", "hbm", pool_bytes, HBM_PEAK)
+        add("ps_importance_pool", pool_bound, pool_bytes, pool_peak)
         if "ps_linear" in ksum:
             add("ps_linear", "mfma", lin_flops_step / (ksum["ps_linear"]["launches"] / a.steps), MFMA_F32_PEAK)
         if "ps_lsh_encode" in ksum:
@@ -273,15 +313,26 @@ def main():
         for mt_call in ("ps_mt19937_raw_stream", "ps_mt19937_random_sample"):     # numpy-stream mode: 8 B written per uniform
             if mt_call in ksum:
                 add(mt_call, "hbm", 8.0 * (steps0 + steps1), HBM_PEAK)
+        # counter traffic per C-ABI call (FETCH_SIZE + WRITE_SIZE of separate --pmc passes over this same command, committed
+        # under profiles/; as reported by rocprofv3 -- see the file's "units" for the gfx950 caveats): shown next to the
+        # algorithmic rate of every call as bytes per launch and GB/s over the launch time measured in THIS run
+        tfile = "pmc_traffic_config5.json" if big else "pmc_traffic_latest.json"
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+            traffic = json.load(open(os.path.join(ROOT, "profiles", tfile)))
         except Exception:
             traffic = {}
-        # `roofline`: the C-ABI call with the largest time per step, whatever bounds it
+        for n, k in kern.items():
+            if isinstance(traffic.get(n), (int, float)) and traffic[n] > 0:
+                k["counter_bytes_per_launch"] = traffic[n]
+                k["counter_GBps"] = traffic[n] / (k["avg_ms"] * 1e-3) / 1e9
+        # `roofline`: the C-ABI call with the largest time per step, whatever bounds it; config 5 exists to show the sampler
+        # where it is HBM-bound (the graph is 66 GB, far beyond the 256 MiB Infinity Cache), so there it is the sampler
         dom = max(kern, key=lambda n: kern[n]["ms_per_step"])
+        if big and "ps_walk_sample_layers" in kern:
+            dom = "ps_walk_sample_layers"
         kd = kern[dom]
-        div = 1e9 if kd["bound"] in ("hbm", "valu") else 1e12
-        unit = {"hbm": "GB/s", "valu": "GB/s", "mfma": "TFLOP/s"}[kd["bound"]]
+        div = 1e9 if kd["bound"] in ("hbm", "valu", "mall") else 1e12
+        unit = {"hbm": "GB/s", "valu": "GB/s", "mall": "GB/s", "mfma": "TFLOP/s"}[kd["bound"]]
         if dom == "ps_hamming_topk_mfma":
             unit = "TOP/s"
         roofline = {"kernel": dom, "bound": kd["bound"], "achieved": kd["achieved"] / div, "peak": kd["peak"] / div,
@@ -290,8 +341,11 @@ def main():
                     "avg_launch_ms": kd["avg_ms"], "algorithmic_per_launch": kd["achieved"] * kd["avg_ms"] * 1e-3,
                     "note": {"ps_hamming_topk_mfma": "exact +-1 contraction on fp4 MFMA; peak = dense fp4 (4 x bf16 per clock at 2.4 GHz); "
                                                      "the call includes the bound pass over 1/5 of the table, counted as overhead",
-                             "ps_walk_sample_layers": "algorithmic bytes per SURVEY 8(d) (rowptr pair + log2(deg) CDF probes + col "
-                                                      "[+ uniform] per taken step), both layers of a start node in one launch"}.get(dom)}
+                             "ps_walk_sample_layers": "algorithmic bytes per SURVEY 8(d) (8 B row bounds + 8 B x ceil(log2(deg+1)) CDF "
+                                                      "probes + 4 B col [+ 8 B uniform] per taken step, T x 8 + 4 B out per start "
+                                                      "node), both layers of a start node in one launch"}.get(dom)}
+        if roofline["bound"] == "mall":
+            roofline["bound"] = "hbm"          # the contract's vocabulary; the on-die bound is named in kernels[*]
         # device kernels behind each C-ABI call (the rows of profiles/*/kernel_stats.csv the timings agree with)
         symbols = {"ps_walk_sample_layers": ["walk_sample_kernel<4>"], "ps_walk_sample": ["walk_sample_kernel<4>"],
                    "ps_importance_pool": ["importance_pool_kernel<4>"],
@@ -306,9 +360,13 @@ def main():
         for n, k in kern.items():
             k["device_kernels"] = symbols.get(n, [])
         if "ps_importance_pool" in kern:
-            kern["ps_importance_pool"]["note"] = ("algorithmic bytes = gathered rows + output (SURVEY 8d); the hidden rows (M x H x 4 = "
-                                                   "60 MB) stay in L2/MALL, so the gathers are not HBM traffic and frac can exceed 1 at large T")
+            kern["ps_importance_pool"]["note"] = (
+                f"algorithmic bytes = gathered rows + output (SURVEY 8d); the gathered table is {pool_table / 1e6:.0f} MB: "
+                + ("it stays in L2 / Infinity Cache, so the bound is the on-die indexed-row gather rate of MI355X_MICROARCH.md "
+                   "(16.8-18.8 TB/s for L2-shared rows, 8.6 TB/s for uniformly random MALL rows; the upper figure is used), not HBM"
+                   if pool_bound == "mall" else "far beyond the Infinity Cache: random 1 KiB rows from HBM"))
         for k in kern.values():
+            assert k["frac"] <= 1.0 + 1e-9, f"a fraction above 1 means the wrong bound: {k}"
             div = 1e12 if k["bound"] == "mfma" else 1e9
             k["achieved"] = k["achieved"] / div
             k["peak"] = k["peak"] / div
@@ -321,14 +379,19 @@ def main():
             "value": value, "unit": "items/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64 cdf / f32 features / fp4 sign planes (exact integer Hamming)", "data": "synthetic",
-            "config": {"workload": f"SYN-25M (ML-25M-shaped: U={U} M={M} R={R}), F=128 H=256 d={D}, 2 GCN layers, "
+            "config": {"workload": (f"SYN-1B (BASELINE config 5: U={U} M={M} R={R} = {2 * R} directed edges, replicated) as rank 0 of "
+                                    f"{sim_ranks} sees it: item shard [{pipe.lo}, {pipe.hi}), gathers of the other ranks' rows stood in "
+                                    f"for by local buffers of the gathered shape (no xGMI time); value = shard items / step; "
+                                    if big else f"SYN-25M (ML-25M-shaped: U={U} M={M} R={R}), ")
+                                   + f"F=128 H=256 d={D}, 2 GCN layers, "
                                    f"W=100 L=2 T={T}, LSH {nbits}-bit, {nq} queries K={a.k}, rng={a.rng}"
                                    + (" (the reference's np.random MT19937 stream generated on device: neighbour ids bit-exact with "
                                       "the reference CPU path)" if a.rng == "numpy" else " (counter-based, shard invariant)")
                                    + (f", BASELINE config {a.config}" if a.config else ""),
-                       "global_items": M, "queries": nq, "parallelism": f"item-shard x{world}"},
-            "embeddings_per_s": M / (phase_ms["embed"] / a.steps * 1e-3),
-            "index_items_per_s": M / (phase_ms["index"] / a.steps * 1e-3),
+                       "global_items": M, "items_per_step": items_per_step, "queries": nq,
+                       "parallelism": f"item-shard x{world}" if not big else f"one rank of item-shard x{sim_ranks}"},
+            "embeddings_per_s": items_per_step / (phase_ms["embed"] / a.steps * 1e-3),
+            "index_items_per_s": items_per_step / (phase_ms["index"] / a.steps * 1e-3),
             "queries_per_s": nq / (phase_ms["query"] / a.steps * 1e-3),
             "phase_ms": {k: round(v / a.steps, 4) for k, v in phase_ms.items()},
             "ms_per_step_instrumented": elapsed_instr / a.steps * 1e3,
@@ -336,9 +399,9 @@ def main():
             "roofline": roofline, "kernels": kern,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq)
+            out["cpu_baseline"] = cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq, big)
             out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        if world == 1:
+        if world == 1 and not big:            # config 5: 5 x 10^9 stream uniforms per shard pass -- Philox only
             out["other_rng_mode"] = other_mode_probe(a, graph, params, LAYERS, M, x_loc, A, T, W, L, nq_local)
         print(json.dumps(out))
     if world > 1:
@@ -377,17 +440,22 @@ def other_mode_probe(a, graph, params, LAYERS, M, x_loc, A, T, W, L, nq_local):
                     "the walk kernel, numpy = the reference's global MT19937 stream generated on the device"}
 
 
-def cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq):
+def cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq, big=False):
     """The CPU oracle (C port of the reference algorithm, pinned by the goldens) timed on this box's host
-    cores on a bounded sample of the same workload; dense layers use torch CPU (what the reference runs)."""
+    cores on a bounded sample of the same workload; dense layers use torch CPU (what the reference runs).
+    Config 5: the sample is 65 536 start items of the shard and 256 queries over the shard's codes (the CSR + CDF, 25 GB,
+    are copied to the host for the oracle), scaled to the shard."""
     from oracle import c_oracle as co
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = max(1, min(threads, co.max_threads()))
     torch.set_num_threads(threads)
     cg = co.Graph.from_arrays(graph.rowptr.cpu().numpy(), graph.col.cpu().numpy(), graph.cdf.cpu().numpy())
-    S = M if a.cpu_sample <= 0 else min(a.cpu_sample, M)
+    n_items = pipe.hi - pipe.lo if big else M                 # what one step embeds
+    if big and a.cpu_sample <= 0:
+        a.cpu_sample = 65536
+    S = n_items if a.cpu_sample <= 0 else min(a.cpu_sample, n_items)
     rs = np.random.RandomState(0)
-    nodes = np.sort(rs.choice(M, size=S, replace=False))
+    nodes = np.sort(rs.choice(n_items, size=S, replace=False)) + (pipe.lo if big else 0)
     t0 = time.perf_counter()
     layers = []
     for call in range(2):
@@ -396,7 +464,9 @@ def cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq):
     t_sample = time.perf_counter() - t0
     P = {k: v.cpu() for k, v in params.items()}
     xs = torch.randn(S, 128)
-    hfull = torch.randn(M, HID)
+    # hidden rows of every item for the pooling gather; config 5: 102 GB of zero pages that are never written (reads of
+    # untouched anonymous memory share the kernel's zero page), so the gather's address stream is the real one
+    hfull = torch.from_numpy(np.zeros((M, HID), dtype=np.float32)) if big else torch.randn(M, HID)
     t0 = time.perf_counter()
     with torch.no_grad():
         h = torch.relu(torch.nn.functional.linear(xs, P["input_proj.weight"], P["input_proj.bias"]))
@@ -414,12 +484,13 @@ def cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq):
     codes_s = np.packbits(bits.numpy(), axis=1, bitorder="little")
     t_enc = time.perf_counter() - t0
     codes_all = pipe.codes.cpu().numpy()                      # the index built by the GPU pass (bit-exact codes)
-    Sq = nq if a.cpu_sample <= 0 else min(2048, nq)
+    Sq = nq if a.cpu_sample <= 0 else min(256 if big else 2048, nq)
     t0 = time.perf_counter()
     co.hamming_topk(codes_all[:Sq], codes_all, a.k, threads=threads)
     t_q = time.perf_counter() - t0
     per_item = (t_sample + t_dense + t_enc) / S
-    step_s = per_item * M + t_q / Sq * nq
+    step_s = per_item * n_items + t_q / Sq * nq
+    Ncodes = codes_all.shape[0]
     # the same port on ONE core (SURVEY 8d asks for both), on a small slice: 256 start items, 16 queries
     S1, Q1 = min(256, S), min(16, Sq)
     torch.set_num_threads(1)
@@ -439,13 +510,13 @@ def cpu_baseline(a, graph, pipe, params, emb, A, M, T, W, L, HID, D, nbits, nq):
     co.hamming_topk(codes_all[:Q1], codes_all, a.k, threads=1)
     t_q1 = (time.perf_counter() - t0) / Q1
     torch.set_num_threads(threads)
-    single = {"value": M / (t_item1 * M + t_q1 * nq), "unit": "items/s", "cores": 1,
-              "sample": f"{S1} start items + {Q1} queries over all {M} codes, scaled to the full step"}
-    return {"value": M / step_s, "unit": "items/s", "cores": threads, "kind": "port", "single_thread": single,
+    single = {"value": n_items / (t_item1 * n_items + t_q1 * nq), "unit": "items/s", "cores": 1,
+              "sample": f"{S1} start items + {Q1} queries over all {Ncodes} codes, scaled to the full step"}
+    return {"value": n_items / step_s, "unit": "items/s", "cores": threads, "kind": "port", "single_thread": single,
             "sample": (f"the whole step: all {S} start items (sampler x2 layers, pooling, dense, LSH encode) + all {Sq} "
-                       f"queries over {M} codes" if S == M and Sq == nq else
+                       f"queries over {Ncodes} codes" if S == n_items and Sq == nq else
                        f"{S} uniformly drawn start items (sampler x2 layers, pooling, dense, LSH encode) + {Sq} queries "
-                       f"over all {M} codes, scaled to the full step"),
+                       f"over all {Ncodes} codes, scaled to the full step"),
             "seconds": {"sampler": round(t_sample, 3), "pool+dense": round(t_dense, 3), "encode": round(t_enc, 4),
                         "query": round(t_q, 3)},
             "embeddings_per_s": 1.0 / per_item, "queries_per_s": Sq / t_q}

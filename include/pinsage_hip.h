@@ -209,6 +209,11 @@ int ps_hamming_topk_mfma(const void *qplanes, int64_t nq, const void *dbplanes, 
  * global k best by (distance, id). */
 int ps_topk_merge(const int32_t *dist_in, const int64_t *ids_in, int P, int64_t nq, int k,
                   int32_t *dist, int64_t *ids, ps_stream_t stream);
+/* The same merge over candidate lists that are not packed back to back: shard p's [nq, k] distances start at
+ * dist_in + p * dist_stride, its ids at ids_in + p * ids_stride (strides in elements, >= nq * k).  Lets every rank write
+ * (ids | dist) into ONE record that a single all-gather exchanges (pinsage_hip/shard.py: [P, nq*k*8 B ids | nq*k*4 B dist]). */
+int ps_topk_merge_strided(const int32_t *dist_in, int64_t dist_stride, const int64_t *ids_in, int64_t ids_stride,
+                          int P, int64_t nq, int k, int32_t *dist, int64_t *ids, ps_stream_t stream);
 
 /* ---- a11: exact search (inference.py:112-118, utils/evaluation.py:106-132) --------------------
  * sim = E[q] . E^T ; optionally sim[q] = -inf ; top-k descending.  vals float[nq,k], ids int64[nq,k].  Any k >= 1

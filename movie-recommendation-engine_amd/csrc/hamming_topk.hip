@@ -164,8 +164,8 @@ __device__ __forceinline__ MergeKey row_min_key(MergeKey v) {
 }
 template <int KPL>
 __global__ __launch_bounds__(256) void topk_select16_kernel(const int32_t *__restrict__ din, const int64_t *__restrict__ iin,
-                                                            int P, int64_t nq, int k, int32_t *__restrict__ dout,
-                                                            int64_t *__restrict__ iout) {
+                                                            int64_t dstride, int64_t istride, int P, int64_t nq, int k,
+                                                            int32_t *__restrict__ dout, int64_t *__restrict__ iout) {
     const int sub = threadIdx.x & 15;
     const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int n = P * k;
@@ -177,9 +177,9 @@ __global__ __launch_bounds__(256) void topk_select16_kernel(const int32_t *__res
         c[r] = NONE;
         if (q < nq && ci < n) {
             const int p = ci / k, t = ci - p * k;
-            const int64_t o = ((int64_t)p * nq + q) * k + t;
-            const int64_t id = iin[o];
-            if (id >= 0) c[r] = MergeKey{(uint32_t)din[o], (uint32_t)((uint64_t)id >> 32), (uint32_t)id};
+            const int64_t o = q * k + t;
+            const int64_t id = iin[(int64_t)p * istride + o];
+            if (id >= 0) c[r] = MergeKey{(uint32_t)din[(int64_t)p * dstride + o], (uint32_t)((uint64_t)id >> 32), (uint32_t)id};
         }
     }
     MergeKey last = NONE;
@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void topk_select16_kernel(const int32_t *__res
 
 // one wave per query: k rounds of (lane-local min over strided candidates) + wave min-reduce.
 __global__ __launch_bounds__(256) void topk_merge_kernel(const int32_t *__restrict__ din, const int64_t *__restrict__ iin,
-                                                         int P, int64_t nq, int k, int32_t *__restrict__ dout,
-                                                         int64_t *__restrict__ iout) {
+                                                         int64_t dstride, int64_t istride, int P, int64_t nq, int k,
+                                                         int32_t *__restrict__ dout, int64_t *__restrict__ iout) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -216,9 +216,9 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const int32_t *__restri
             int64_t bi = 0x7fffffffffffffffll;
             for (int c = lane; c < n; c += 64) {
                 const int p = c / k, t = c - p * k;
-                const int64_t o = ((int64_t)p * nq + qi) * k + t;
-                const int32_t d = din[o];
-                const int64_t id = iin[o];
+                const int64_t o = qi * k + t;
+                const int32_t d = din[(int64_t)p * dstride + o];
+                const int64_t id = iin[(int64_t)p * istride + o];
                 if (id < 0) continue;
                 const bool after = (d > ld) || (d == ld && id > li);
                 const bool better = (d < bd) || (d == bd && id < bi);
@@ -277,26 +277,37 @@ extern "C" size_t ps_hamming_topk_workspace_bytes(int64_t nq, int64_t N, int cs,
     return (size_t)s * (size_t)nq * (size_t)k * (sizeof(int32_t) + sizeof(int64_t)) + 512;
 }
 
-extern "C" int ps_topk_merge(const int32_t *dist_in, const int64_t *ids_in, int P, int64_t nq, int k, int32_t *dist,
-                             int64_t *ids, ps_stream_t stream) {
+extern "C" int ps_topk_merge_strided(const int32_t *dist_in, int64_t dist_stride, const int64_t *ids_in, int64_t ids_stride,
+                                     int P, int64_t nq, int k, int32_t *dist, int64_t *ids, ps_stream_t stream) {
     if (P <= 0 || nq < 0 || k <= 0) return PS_EINVAL;
     if (nq == 0) return PS_OK;
     if (!dist_in || !ids_in || !dist || !ids) return PS_EINVAL;
+    if (dist_stride < nq * k || ids_stride < nq * k) return PS_EINVAL;     // shard lists must not overlap
     const int64_t n = (int64_t)P * k;
     hipStream_t st = ps_stream(stream);
     if (n <= 256) {
         const unsigned g16 = (unsigned)ps_cdiv(nq, 16);                          // 16 lanes per query, 256 threads per block
-        if (n <= 32) hipLaunchKernelGGL(topk_select16_kernel<2>, dim3(g16), dim3(256), 0, st, dist_in, ids_in, P, nq, k, dist, ids);
-        else if (n <= 64) hipLaunchKernelGGL(topk_select16_kernel<4>, dim3(g16), dim3(256), 0, st, dist_in, ids_in, P, nq, k, dist, ids);
-        else if (n <= 128) hipLaunchKernelGGL(topk_select16_kernel<8>, dim3(g16), dim3(256), 0, st, dist_in, ids_in, P, nq, k, dist, ids);
-        else hipLaunchKernelGGL(topk_select16_kernel<16>, dim3(g16), dim3(256), 0, st, dist_in, ids_in, P, nq, k, dist, ids);
+#define PS_SEL16(KPL_) hipLaunchKernelGGL(topk_select16_kernel<KPL_>, dim3(g16), dim3(256), 0, st, dist_in, ids_in, dist_stride, \
+                                          ids_stride, P, nq, k, dist, ids)
+        if (n <= 32) PS_SEL16(2);
+        else if (n <= 64) PS_SEL16(4);
+        else if (n <= 128) PS_SEL16(8);
+        else PS_SEL16(16);
+#undef PS_SEL16
     } else {
         int64_t grid = ps_cdiv(nq, 4);
         if (grid > 256 * 16) grid = 256 * 16;
-        hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)grid), dim3(256), 0, st, dist_in, ids_in, P, nq, k, dist, ids);
+        hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)grid), dim3(256), 0, st, dist_in, ids_in, dist_stride, ids_stride, P,
+                           nq, k, dist, ids);
     }
     PS_CHECK_LAUNCH();
     return PS_OK;
+}
+
+extern "C" int ps_topk_merge(const int32_t *dist_in, const int64_t *ids_in, int P, int64_t nq, int k, int32_t *dist,
+                             int64_t *ids, ps_stream_t stream) {
+    if (nq < 0 || k <= 0) return PS_EINVAL;
+    return ps_topk_merge_strided(dist_in, nq * k, ids_in, nq * k, P, nq, k, dist, ids, stream);
 }
 
 extern "C" int ps_hamming_topk(const uint8_t *qcodes, int64_t nq, const uint8_t *codes, int64_t N, int cs, int k,

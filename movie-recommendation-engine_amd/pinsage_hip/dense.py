@@ -101,8 +101,9 @@ def hamming_mfma_supported(nq, N, cs, k):
     return int(nv.lib().ps_hamming_topk_mfma_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(cs), nv.i32(k))) > 0
 
 
-def hamming_topk(qcodes, codes, k, id_offset=0, planes=None, use_mfma=True):
+def hamming_topk(qcodes, codes, k, id_offset=0, planes=None, use_mfma=True, out=None):
     """-> (dist int32[nq,k], ids int64[nq,k]): k smallest by (distance, id), ascending.
+    out=(dist, ids): write into these contiguous device tensors (a rank's candidate record, shard.py) instead of new ones.
     `planes` = lsh_expand(codes), kept by the index: the scan then runs as an exact int8 MFMA contraction when the
     shape is served (ps_hamming_topk_mfma); otherwise, and for `use_mfma=False`, the popcount kernel runs.  Both
     return the same bits."""
@@ -111,10 +112,21 @@ def hamming_topk(qcodes, codes, k, id_offset=0, planes=None, use_mfma=True):
     codes = codes.contiguous()
     nq, cs = int(qcodes.size(0)), int(qcodes.size(1))
     N = int(codes.size(0))
+    if out is not None:
+        dist, ids = out
+        if (tuple(dist.shape) != (nq, k) or tuple(ids.shape) != (nq, k) or dist.dtype != torch.int32
+                or ids.dtype != torch.int64 or not dist.is_contiguous() or not ids.is_contiguous()):
+            raise ValueError("out must be contiguous (int32 [nq, k], int64 [nq, k])")
     if k > HAMMING_MAX_K:
-        return _hamming_topk_large_k(qcodes, codes, k, id_offset)
-    dist = torch.empty((nq, k), dtype=torch.int32, device=qcodes.device)
-    ids = torch.empty((nq, k), dtype=torch.int64, device=qcodes.device)
+        d, i = _hamming_topk_large_k(qcodes, codes, k, id_offset)
+        if out is None:
+            return d, i
+        dist.copy_(d)
+        ids.copy_(i)
+        return dist, ids
+    if out is None:
+        dist = torch.empty((nq, k), dtype=torch.int32, device=qcodes.device)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=qcodes.device)
     L = nv.lib()
     if use_mfma and planes is not None:
         wsb = int(L.ps_hamming_topk_mfma_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(cs), nv.i32(k)))
@@ -172,6 +184,24 @@ def topk_merge(dist_in, ids_in):
     with torch.cuda.device(dist_in.device):
         nv.call("ps_topk_merge", nv.ptr(dist_in), nv.ptr(ids_in), nv.i32(P), nv.i64(nq), nv.i32(k), nv.ptr(dist),
                                         nv.ptr(ids), nv.stream())
+    return dist, ids
+
+
+def topk_merge_records(records, nq, k):
+    """records uint8 [P, rec]: shard p's candidate record = [nq*k int64 ids | nq*k int32 distances | pad to 16 B], exactly
+    as one all-gather delivers them -> global (dist int32[nq,k], ids int64[nq,k]) by (distance, id); no repacking."""
+    if records.dtype != torch.uint8 or records.dim() != 2 or not records.is_contiguous():
+        raise ValueError("records must be a contiguous uint8 [P, record_bytes] tensor")
+    P, rec = int(records.size(0)), int(records.size(1))
+    n = int(nq) * int(k)
+    if rec < 12 * n or rec % 8 != 0:
+        raise ValueError("record too short or not 8-byte aligned")
+    dist = torch.empty((nq, k), dtype=torch.int32, device=records.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=records.device)
+    base = records.data_ptr()
+    with torch.cuda.device(records.device):
+        nv.call("ps_topk_merge_strided", nv.C.c_void_p(base + 8 * n), nv.i64(rec // 4), nv.C.c_void_p(base), nv.i64(rec // 8),
+                nv.i32(P), nv.i64(int(nq)), nv.i32(int(k)), nv.ptr(dist), nv.ptr(ids), nv.stream())
     return dist, ids
 
 

@@ -43,26 +43,67 @@ class _Gather:
         return self.out if self.dev is None else self.out.to(self.dev)
 
 
+class Comm:
+    """The row-shard all-gathers of one ShardedPinSage.  Receive buffers (and the zero-padded send buffer of a short last
+    shard) are allocated once per (tag, shape, dtype) and reused by every step: the steady state allocates nothing and
+    pads nothing.  A buffer is only rewritten by the next gather with the same tag, which is enqueued behind every kernel
+    that read it (RCCL's collective stream waits for the current stream at issue).
+
+    standin=(rank, world): no process group -- this GPU plays ONE rank of `world`; a gather copies the local shard into its
+    slot of a buffer of the gathered shape (the other ranks' rows stay as they are: zeros).  What a rank computes per step is
+    then exactly what it computes in the real job (bench.py --config 5, tools/shard_sim.py); only the xGMI time is missing."""
+
+    def __init__(self, group=None, standin=None):
+        self.group = group
+        self.standin = standin
+        if standin is not None:
+            self.rank, self.world = int(standin[0]), int(standin[1])
+        elif dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            self.rank, self.world = 0, 1
+        self._bufs = {}
+
+    def _buf(self, kind, tag, shape, dtype, device, zero=False):
+        key = (kind, tag, tuple(shape), dtype, str(device))
+        b = self._bufs.get(key)
+        if b is None:
+            b = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=device)
+            self._bufs[key] = b
+        return b
+
+    def gather_rows_async(self, t, chunk, tag="rows"):
+        """[n_local, ...] (n_local <= chunk) -> handle; rank r's rows start at r * chunk.  With RCCL the collective runs
+        asynchronously on its own stream (overlaps kernels enqueued afterwards); gloo has no device all_gather, so
+        device tensors are staged through the host synchronously (tests / rehearsal only)."""
+        if self.world == 1:
+            return _Gather(t)
+        rest = tuple(t.shape[1:])
+        if self.standin is not None:
+            out = self._buf("recv", tag, (self.world * chunk,) + rest, t.dtype, t.device, zero=True)
+            out[self.rank * chunk: self.rank * chunk + t.size(0)].copy_(t)
+            return _Gather(out)
+        if t.size(0) == chunk and t.is_contiguous():
+            src = t                                          # full shard (every rank but possibly the last): no copy
+        else:
+            src = self._buf("send", tag, (chunk,) + rest, t.dtype, t.device, zero=True)   # zeroed once; the tail stays zero
+            src[: t.size(0)].copy_(t)
+        if _backend(self.group) == "gloo" and src.is_cuda:
+            out = torch.empty((self.world * chunk,) + rest, dtype=t.dtype)
+            dist.all_gather_into_tensor(out, src.cpu().contiguous(), group=self.group)
+            return _Gather(out, dev=t.device)
+        out = self._buf("recv", tag, (self.world * chunk,) + rest, t.dtype, src.device)
+        work = dist.all_gather_into_tensor(out, src, group=self.group, async_op=True)
+        return _Gather(out, work)
+
+    def gather_rows(self, t, chunk, tag="rows"):
+        return self.gather_rows_async(t, chunk, tag).wait()
+
+
 def all_gather_rows_async(t, chunk, group=None):
-    """[n_local, ...] (n_local <= chunk) -> handle; rank r's rows start at r * chunk.  With RCCL the collective
-    runs asynchronously on its own stream (overlaps kernels enqueued afterwards); gloo has no CUDA all_gather,
-    so it is staged through the host synchronously (tests / rehearsal only)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return _Gather(t)
-    world = dist.get_world_size(group)
-    if t.size(0) == chunk and t.is_contiguous():
-        pad = t                                          # full shard (all ranks but possibly the last): no copy
-    else:
-        pad = torch.zeros((chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        pad[: t.size(0)] = t
-    if _backend(group) == "gloo" and pad.is_cuda:
-        src = pad.cpu()
-        out = torch.empty((world * chunk,) + tuple(t.shape[1:]), dtype=t.dtype)
-        dist.all_gather_into_tensor(out, src.contiguous(), group=group)
-        return _Gather(out, dev=t.device)
-    out = torch.empty((world * chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=pad.device)
-    work = dist.all_gather_into_tensor(out, pad.contiguous(), group=group, async_op=True)
-    return _Gather(out, work)
+    """module-level form (tests, callers without a ShardedPinSage): fresh receive buffer per call"""
+    c = Comm(group)
+    return c.gather_rows_async(t, chunk)
 
 
 def all_gather_rows(t, chunk, group=None):
@@ -119,26 +160,32 @@ class HipOps:
     def lsh_planes(self, codes):
         return dense.lsh_expand(codes)
 
-    def hamming_topk(self, q, codes, k, id_offset, planes=None):
-        return dense.hamming_topk(q, codes, k, id_offset=id_offset, planes=planes)
+    def hamming_topk(self, q, codes, k, id_offset, planes=None, out=None):
+        return dense.hamming_topk(q, codes, k, id_offset=id_offset, planes=planes, out=out)
 
     def topk_merge(self, d, i):
         return dense.topk_merge(d, i)
+
+    def topk_merge_records(self, records, nq, k):
+        """records uint8 [P, rec]: every rank's [nq*k int64 ids | nq*k int32 distances | pad] as gathered"""
+        return dense.topk_merge_records(records, nq, k)
 
 
 class ShardedPinSage:
     """get_embeddings + LSH build/search over `world` item shards."""
 
-    def __init__(self, params, num_layers, sampler, num_items, ops=None, group=None):
+    def __init__(self, params, num_layers, sampler, num_items, ops=None, group=None, standin=None):
+        """standin=(rank, world): play one rank of a `world`-rank job on this GPU without a process group (see Comm)."""
         self.P = params                   # state_dict tensors (replicated), on the compute device
         self.num_layers = num_layers
         self.sampler = sampler
         self.M = int(num_items)
         self.ops = ops if ops is not None else HipOps()
         self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.comm = Comm(group, standin=standin)
+        self.rank, self.world = self.comm.rank, self.comm.world
         self.lo, self.hi, self.chunk = shard_range(self.M, self.rank, self.world)
+        self._nodes = {}                   # device -> arange(lo, hi): made once, not per step
         self.overlap_sampling = False      # measured: no gain on MI355X (2.69 vs 2.65 ms per pass)
         self.fuse_self = True
         self._streams = {}
@@ -181,7 +228,13 @@ class ShardedPinSage:
     def _embed(self, x_local, T, x_full=None):
         ops, P = self.ops, self.P
         dev = x_local.device
-        nodes = torch.arange(self.lo, self.hi, dtype=torch.int64, device=dev)
+        fused = (not (self.overlap_sampling and x_local.is_cuda)) and hasattr(ops, "sample_layers") \
+            and hasattr(self.sampler, "sample_batches")
+        nodes = None
+        if not fused:                          # the fused launch takes the item range itself
+            nodes = self._nodes.get(str(dev))
+            if nodes is None:
+                nodes = self._nodes[str(dev)] = torch.arange(self.lo, self.hi, dtype=torch.int64, device=dev)
         # fresh neighbour samples per layer, drawn in the reference's order (:271-275); no communication.
         # Layer i+1's sampling and lin_self are enqueued while layer i's hidden rows are being all-gathered.
         shard = (self.M, self.lo) if self.world > 1 else None
@@ -190,7 +243,6 @@ class ShardedPinSage:
         # order) while the main stream runs the projections; each pooling waits for its own batch only.
         side = self._side_stream(dev) if (self.overlap_sampling and x_local.is_cuda) else None
         batches, ready = [], []
-        fused = side is None and hasattr(ops, "sample_layers") and hasattr(self.sampler, "sample_batches")
         if fused:
             batches = list(ops.sample_layers(self.sampler, self.lo, self.hi, T, self.num_layers, shard))
         elif side is not None:
@@ -211,7 +263,7 @@ class ShardedPinSage:
             pending = _Gather(h_all)
         else:
             h = ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
-            pending = all_gather_rows_async(h, self.chunk, self.group)
+            pending = self.comm.gather_rows_async(h, self.chunk, "h")
         for i in range(self.num_layers):
             if side is None and not fused and i + 1 < self.num_layers:
                 batches.append(self._sample(nodes, T, shard))       # enqueued while layer i's rows are gathered
@@ -229,7 +281,7 @@ class ShardedPinSage:
             h_neigh = ops.pool(h_full, batches[i], self.M - 1)
             h = ops.linear(a_in, W1, b1, x2=h_neigh, W2=Wu[:, H:], relu=True, l2norm=True)
             if i + 1 < self.num_layers:
-                pending = all_gather_rows_async(h, self.chunk, self.group)
+                pending = self.comm.gather_rows_async(h, self.chunk, "h")
         return ops.linear(h, P["output_proj.weight"], P["output_proj.bias"], l2norm=True)
 
     # -- LSH: LSHIndex.build / .search (utils/nearest_neighbors.py:28-68) over code shards -------------
@@ -242,18 +294,33 @@ class ShardedPinSage:
 
     def search(self, q_local, k):
         """q_local: this rank's query embeddings [nq_local, D] (every rank contributes the same count).
-        Returns (dist int32[nq, k], ids int64[nq, k]) for ALL queries, rank-major, on every rank."""
+        Returns (dist int32[nq, k], ids int64[nq, k]) for ALL queries, rank-major, on every rank.
+        N > 1: the scan writes its (ids | distances) straight into this rank's candidate record, ONE all-gather exchanges
+        the records ([P, record] bytes, receive buffer allocated once) and ps_topk_merge_strided reads the gathered
+        records in place: no stack / dtype conversion / reshape kernels around the exchange."""
         ops = self.ops
         qc = ops.lsh_encode(q_local, self.A)
         nq_local = qc.size(0)
-        qc_all = all_gather_rows(qc, nq_local, self.group)
-        if getattr(self, "planes", None) is not None:
-            d, i = ops.hamming_topk(qc_all, self.codes, k, self.lo, planes=self.planes)
-        else:
-            d, i = ops.hamming_topk(qc_all, self.codes, k, self.lo)
+        qc_all = self.comm.gather_rows(qc, nq_local, "qcodes")
+        planes = getattr(self, "planes", None)
         if self.world == 1:
-            return d, i
+            return (ops.hamming_topk(qc_all, self.codes, k, self.lo, planes=planes) if planes is not None
+                    else ops.hamming_topk(qc_all, self.codes, k, self.lo))
         nq = qc_all.size(0)
-        both = torch.stack([d.to(torch.int64), i]).reshape(1, 2, nq, k)       # one collective for (dist, id)
-        both_all = all_gather_rows(both, 1, self.group)                       # [P, 2, nq, k]
-        return ops.topk_merge(both_all[:, 0].to(torch.int32).contiguous(), both_all[:, 1].contiguous())
+        n = nq * k
+        rec = (12 * n + 15) // 16 * 16                                        # [n x int64 ids | n x int32 dist | pad]
+        mine = self.comm._buf("cand", "mine", (1, rec), torch.uint8, qc_all.device, zero=True)
+        ids_v = mine[0, : 8 * n].view(torch.int64).view(nq, k)
+        dist_v = mine[0, 8 * n: 12 * n].view(torch.int32).view(nq, k)
+        try:
+            ops.hamming_topk(qc_all, self.codes, k, self.lo, planes=planes, out=(dist_v, ids_v))
+        except TypeError:                                                       # test backends: plain (q, codes, k, offset)
+            d, i = ops.hamming_topk(qc_all, self.codes, k, self.lo)
+            dist_v.copy_(d)
+            ids_v.copy_(i)
+        allc = self.comm.gather_rows(mine, 1, "cand")                           # [P, rec] bytes
+        if hasattr(ops, "topk_merge_records"):
+            return ops.topk_merge_records(allc, nq, k)
+        d_all = torch.stack([allc[p, 8 * n: 12 * n].view(torch.int32).view(nq, k) for p in range(self.world)])
+        i_all = torch.stack([allc[p, : 8 * n].view(torch.int64).view(nq, k) for p in range(self.world)])
+        return ops.topk_merge(d_all, i_all)

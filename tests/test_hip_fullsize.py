@@ -139,6 +139,17 @@ def test_lsh_roundtrip_and_sharded_search_full_size(D, nbits):
                                 planes=dense.lsh_expand(codes[s:s + chunk].contiguous())) for s in range(0, M, chunk)]
     dm, im = dense.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert torch.equal(dm, dist) and torch.equal(im, ids)
+    # the multi-GPU exchange format: every shard's scan writes (ids | distances) straight into its candidate record, the
+    # gathered records are merged in place (ps_topk_merge_strided) -- same answer, no repacking
+    nq, n = q.numel(), q.numel() * k
+    rec = (12 * n + 15) // 16 * 16
+    records = torch.zeros((8, rec), dtype=torch.uint8, device=dev)
+    for p, s in enumerate(range(0, M, chunk)):
+        out = (records[p, 8 * n: 12 * n].view(torch.int32).view(nq, k), records[p, : 8 * n].view(torch.int64).view(nq, k))
+        part = codes[s:s + chunk].contiguous()
+        dense.hamming_topk(codes[q], part, k, id_offset=s, planes=dense.lsh_expand(part), out=out)
+    dr, ir = dense.topk_merge_records(records, nq, k)
+    assert torch.equal(dr, dist) and torch.equal(ir, ids)
 
 
 @pytest.mark.parametrize("T,D,rng", [(10, 256, "philox"), (10, 128, "numpy"), (50, 256, "numpy")])
@@ -277,3 +288,94 @@ def test_device_ingest_full_size_equals_host_factorize():
     assert np.array_equal(mu_d.cpu().numpy(), np.asarray(mu_h)) and np.array_equal(uu_d.cpu().numpy(), np.asarray(uu_h))
     dg = DeviceGraph(ei_d, ew_d)
     assert dg.E == 2 * R and dg.V == len(mu_h) + len(uu_h) and not dg.has_reachable_sink
+
+
+def test_config5_full_scale_shard_sampling_and_oracle_parity():
+    """BASELINE config 5 at its real size, as one of its eight ranks sees it: the replicated graph of 100 M items, 10 M users
+    and 10^9 ratings (2 x 10^9 directed edges, 66 GB resident without the 128 GB of bucket records, so every step takes the
+    packed-block search), Philox uniforms, item shards of 12.5 M.  Every shard of the catalogue is sampled (both GCN layers
+    in one launch) and held to the size-independent properties; the C oracle then replays ~1 100 start nodes -- the
+    maximum-degree item rows (1.4 M edges: 21-probe searches), the maximum-degree user rows and random items of every shard
+    -- on a host copy of the CSR + CDF, and the pinned python oracle rebuilds the CDF of the heaviest rows from their
+    weights (reference utils/random_walk.py:72-79: w / w.sum(), cumsum, searchsorted)."""
+    import os
+    import time
+    from oracle import c_oracle as co
+    from oracle import pinsage_oracle as orc
+    from pinsage_hip import sampling, synth
+    from pinsage_hip.graph import DeviceGraph
+    dev = torch.device("cuda")
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info(dev)[0]
+    if free < 200e9:
+        pytest.skip(f"config 5 needs ~170 GB of HBM while the graph is built; {free / 1e9:.0f} GB free")
+    U, M, R, P = 10_000_000, 100_000_000, 1_000_000_000, 8
+    T, W, L = 10, 100, 2
+    t0 = time.time()
+    ei, ew = synth.bipartite_ratings(U, M, R, seed=20240601, device=dev)
+    g = DeviceGraph(ei, ew, buckets=False)
+    del ei, ew
+    torch.cuda.empty_cache()
+    print(f"config 5 graph: V={g.V} E={g.E} max degree {g.max_degree}, {g.nbytes() / 1e9:.1f} GB resident, "
+          f"built in {time.time() - t0:.1f} s", flush=True)
+    assert g.V == M + U and g.E == 2 * R and g.buckets is None and not g.has_reachable_sink
+    deg = g.rowptr[1:] - g.rowptr[:-1]
+    assert int(deg[:M].min()) >= 1 and g.max_degree == int(deg.max()) > 1_000_000
+    chunk = M // P
+    arT = torch.arange(T, device=dev)[None, :]
+    gen = torch.Generator(device=dev).manual_seed(5)
+    picked = []                                           # random start items of every shard for the oracle replay
+    for r in range(P):
+        lo, hi = r * chunk, (r + 1) * chunk
+        two = sampling.walk_sample_layers(g, range(lo, hi), T, 2, W, L, rng="philox", seed=42, call=0)
+        if r == 0:                                        # determinism: the same launch again
+            again = sampling.walk_sample_layers(g, range(lo, hi), T, 2, W, L, rng="philox", seed=42, call=0)
+            for x, y in zip(two, again):
+                assert torch.equal(x.ids, y.ids) and torch.equal(x.counts, y.counts) and torch.equal(x.nvalid, y.nvalid)
+            del again
+        for layer, b in enumerate(two):
+            nv = b.nvalid.long()
+            valid = arT < nv[:, None]
+            assert bool((nv >= 1).all()) and bool((nv <= T).all())           # every item has out-edges
+            assert bool(((b.ids >= 0) & (b.ids < g.V))[valid].all()) and bool((b.ids[~valid] == -1).all())
+            c = b.counts.long()
+            assert bool((c[valid] >= 1).all()) and bool((c[~valid] == 0).all()) and bool((c.sum(1) <= W * L).all())
+            assert bool((c[:, :-1] >= c[:, 1:]).all())                       # visit counts descending
+            srt = torch.sort(b.ids, dim=1).values
+            assert bool(((srt[:, 1:] != srt[:, :-1]) | (srt[:, 1:] < 0)).all())   # no duplicate ids in a row
+            del srt, c, valid
+            # slice / batching invariance: a sub-range of the shard and a scattered batch give the same rows
+            off = int(torch.randint(0, chunk - 4096, (1,), generator=gen, device=dev))
+            s = sampling.walk_sample(g, torch.arange(lo + off, lo + off + 4096, device=dev), T, W, L, rng="philox", seed=42,
+                                     call=layer)
+            assert torch.equal(s.ids, b.ids[off:off + 4096]) and torch.equal(s.counts, b.counts[off:off + 4096])
+            idx = torch.randint(0, chunk, (2048,), generator=gen, device=dev)
+            s = sampling.walk_sample(g, lo + idx, T, W, L, rng="philox", seed=42, call=layer)
+            assert torch.equal(s.ids, b.ids[idx]) and torch.equal(s.counts, b.counts[idx])
+        assert not torch.equal(two[0].ids, two[1].ids)                       # fresh draws per layer
+        picked.append(lo + torch.randint(0, chunk, (128,), generator=gen, device=dev))
+        del two
+    # ---- oracle parity on the heaviest rows + random items of every shard ----
+    host_gb = (os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")) / 1e9
+    if host_gb < 64:
+        pytest.skip(f"oracle replay needs a 25 GB host copy of the CSR + CDF; this host has {host_gb:.0f} GB")
+    top_items = torch.topk(deg[:M], 32).indices
+    top_users = M + torch.topk(deg[M:], 32).indices
+    nodes = torch.cat([top_items, top_users] + picked).cpu().numpy()
+    # the CDF of the four heaviest rows, rebuilt by the pinned python oracle from the row's weights
+    for v in [int(top_items[0]), int(top_items[1]), int(top_users[0]), int(top_users[1])]:
+        lo, hi = int(g.rowptr[v]), int(g.rowptr[v + 1])
+        w = g.wsorted[lo:hi].cpu().numpy()
+        ref = orc.cdf_from_csr(np.array([0, hi - lo], dtype=np.int64), w)
+        assert np.array_equal(g.cdf[lo:hi].cpu().numpy(), ref), f"CDF of row {v} (degree {hi - lo})"
+    t0 = time.time()
+    cg = co.Graph.from_arrays(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.cdf.cpu().numpy())
+    print(f"host copy of rowptr / col / cdf: {time.time() - t0:.1f} s", flush=True)
+    dn = torch.from_numpy(nodes).to(dev)
+    threads = max(1, min(16, co.max_threads()))
+    for call in (0, 1):
+        got = sampling.walk_sample(g, dn, T, W, L, rng="philox", seed=42, call=call)
+        ids, counts, nvalid, _, _, probes = co.walk_sample(cg, nodes, T, L, W, philox=(42, call), threads=threads)
+        assert np.array_equal(got.ids.cpu().numpy().astype(np.int64), ids)
+        assert np.array_equal(got.counts.cpu().numpy(), counts) and np.array_equal(got.nvalid.cpu().numpy(), nvalid)
+    print(f"oracle parity on {nodes.size} start nodes (degrees up to {int(deg[top_items[0]])}), {probes} CDF probes", flush=True)

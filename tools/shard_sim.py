@@ -26,21 +26,8 @@ P = {k: v.detach().float().contiguous() for k, v in model.state_dict().items()}
 x_full = torch.randn(M, 128, device=dev)
 A = torch.from_numpy(lsh_rotation_matrix(256, 512)).to(dev)
 for world in [int(w) for w in a.worlds.split(",")]:
-    pipe = S.ShardedPinSage(P, 2, smp, M)
     rank = min(a.rank, world - 1)
-    pipe.world, pipe.rank = world, rank
-    pipe.lo, pipe.hi, pipe.chunk = S.shard_range(M, rank, world)
-    full = {}
-
-    def fake_gather(t, chunk, group=None, _w=world):
-        key = (tuple(t.shape[1:]), t.dtype, chunk)
-        if key not in full:
-            full[key] = torch.zeros((_w * chunk,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        full[key][: t.size(0)] = t
-        return S._Gather(full[key])
-
-    S.all_gather_rows_async = fake_gather
-    S.all_gather_rows = lambda t, chunk, group=None: fake_gather(t, chunk).wait()
+    pipe = S.ShardedPinSage(P, 2, smp, M, standin=(rank, world))      # gathers = copies into buffers of the gathered shape
     x_loc = x_full[pipe.lo:pipe.hi].contiguous()
     nq_local = 10000 // world
 
