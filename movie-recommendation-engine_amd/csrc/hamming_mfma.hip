@@ -20,20 +20,27 @@
 // contraction is over matching bits whatever k permutation the hardware applies inside a step.
 //
 // Three passes (all exact; no host synchronisation):
-//   bound   : over the first `sample` items every lane keeps the KM best "minimum of a 16-item group" distances
-//             (branch-free min/max insertion network in registers); the k-th smallest group minimum over a query's
-//             lanes bounds its k-th best distance from above (k distinct groups = k distinct items).
-//   collect : over ALL items, a 32 x 32 tile of dots is 16 MFMAs; lane = query, registers = items, so the admission
-//             test is ONE per-lane threshold: max3 tree + compare, and almost every tile ends there.  Hits are appended
-//             to a lane-private LDS column (no cross-lane traffic, no atomics); a column that fills up is compacted to
-//             its k best and the lane's threshold tightened (exact: ids ascend during the sweep).
+//   bound   : over the first `sample` items every lane keeps the KM best "maximum dot of a 16-item group" values
+//             (KM = 4 when a query's sample is seen by enough lanes; the insertion network runs only for tiles in which some
+//             lane's list changes); the k-th smallest group minimum over a query's lanes bounds its k-th best distance from
+//             above (k distinct groups = k distinct items).
+//   collect : over ALL items, a 32 x 32 tile of dots is KS MFMAs; lane = query, registers = items, so the admission
+//             test is ONE per-lane threshold: an 11-instruction max tree + compare.  The accumulators start at
+//             BIAS + r / 16, so an element carries its row in its fraction bits and the maximum of a hit lane is appended
+//             to the lane's candidate column without looking at the other 15; a second hit in the same lane and tile is
+//             detected exactly by two second-largest-group-maximum tests and only then are all rows walked.  A column that
+//             fills up is compacted to its k best and the lane's threshold tightened (exact: ids ascend during the sweep).
 //   merge   : every slice leaves one sorted k-list per query (the two lanes of a query merge theirs in LDS);
 //             slice_merge_kernel merges them by (distance, row): 16 lanes per query, k rounds of a DPP row minimum
-//             (slice_merge64_kernel, one wave per query, when few queries over a large table are cut into 17..64 slices:
-//             1 024 queries x 10^6 codes 1.53 -> 0.42 ms, 64 x 59 047 0.129 -> 0.067 ms; tools/hamming_crossover.py).
-// One workgroup = 8 waves = 256 queries x one slice of the table; item tiles are shared through a 3-deep LDS ring
-// (counted vmcnt, raw s_barrier); waves 4-7 run their tile epilogue one tile late so that the two waves of a SIMD
-// alternate between the matrix pipe and the VALU instead of meeting at both.
+//             (slice_merge64_kernel, one wave per query, when few queries over a large table are cut into 17..64 slices).
+// One workgroup = 8 waves = 256 queries x one slice of the table; item tiles come through a 4-deep LDS ring (LDS-DMA, counted
+// vmcnt, raw s_barrier) and two register sets of item fragments (the ds_reads of entry i + 1 run under the MFMAs of entry i);
+// waves 4-7 run their tile epilogue one entry late so that the two waves of a SIMD alternate between the matrix pipe and
+// the VALU instead of meeting at both.
+// Where the time goes (r03, 10 000 x 59 047 x 512 bit, k = 11, tools/hm_probe_run.sh): sweep without any epilogue 91 us (the
+// 4.73 M MFMAs alone are 79 us at the measured 16 ns each), + the usual exit of every tile 47 us, + the hit path (2/3 of the
+// tiles have a hit in one of the wave's 1 024 elements) 100 us: with two waves per SIMD an epilogue instruction costs the
+// wave ~13-15 cycles whatever it is, so the pass is bound by the epilogue's instruction count, not by the matrix pipe.
 #include "ps_common.h"
 
 namespace {
@@ -47,12 +54,24 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef PS_HM_DEBUG
 #define PS_HM_DEBUG 0
 #endif
+#if PS_HM_DEBUG & 32      // event counters of the collect pass (tools/hm_counts.py): tiles, slow-path entries, group entries, row ballots, appends, compactions
+__device__ unsigned long long ps_hm_counts[8];
+#define PS_HM_COUNT(slot, n) do { if (MODE == 1 && lane == 0) atomicAdd(&ps_hm_counts[slot], (unsigned long long)(n)); } while (0)
+extern "C" int ps_debug_hm_counts(unsigned long long *host, int reset) {
+    unsigned long long z[8] = {};
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(ps_hm_counts), z, sizeof(z));
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ps_hm_counts), sizeof(z));
+}
+#else
+#define PS_HM_COUNT(slot, n) do {} while (0)
+#endif
 constexpr uint32_t EMPTY_KEY = 0xffffffffu;
-constexpr int NBUF = 3;
-constexpr int CAP = 48;                    // slots of a lane's candidate column (LDS); compacted beyond 32
+constexpr int NBUF = 4;                    // ring entries: one being multiplied (from registers), one being read into registers, two in flight
 constexpr int WAVES = 8;
-constexpr int IT = 2;                       // item tiles (32 codes each) per ring entry = per barrier; planes are padded to whole entries
+constexpr int PAD_TILES = 4;               // plane tables are padded to whole ring entries (2 or 4 item tiles of 32 codes)
 constexpr float NO_DOT = -1048576.0f;       // "no item": below every real dot (|dot| <= 1024)
+// item tiles per ring entry = per barrier: 16 MFMAs per wave and barrier for 512- and 256-bit codes
+template <int KS> struct EntryTiles { static constexpr int value = KS >= 4 ? 2 : 4; };
 
 // ---- sign planes ------------------------------------------------------------------------------------------------
 // one thread = one 16-byte piece (tile, step, lane): the 32 code bits of word 2 s + (lane >> 5) as 32 fp4 nibbles
@@ -85,6 +104,7 @@ struct HArgs {
     int64_t tiles_per_slice;
     int nqb, slices;
     int k, nbits, shift;
+    int cap;                        // collect: slots of a lane's candidate column (k + 16 <= cap)
     int64_t id_offset;
     const int32_t *thr0;            // collect: per-query admission bound (hamming distance, inclusive)
     int32_t *bl;                    // bound: [nq][slices * 2][KM] group-minimum distances, ascending
@@ -105,13 +125,6 @@ __device__ __forceinline__ void lds_dma16(const void *gptr, uint32_t lds_byte_of
 }
 #pragma clang diagnostic pop
 
-__device__ __forceinline__ float max16(const v16f &a) {
-    float m = fmaxf(fmaxf(a[0], a[1]), a[2]);
-    m = fmaxf(fmaxf(m, a[3]), a[4]);  m = fmaxf(fmaxf(m, a[5]), a[6]);   m = fmaxf(fmaxf(m, a[7]), a[8]);
-    m = fmaxf(fmaxf(m, a[9]), a[10]); m = fmaxf(fmaxf(m, a[11]), a[12]); m = fmaxf(fmaxf(m, a[13]), a[14]);
-    return fmaxf(m, a[15]);
-}
-
 // one K step: 32 x 32 x 64 signs; only the first four registers of the 8-register operands are read for fp4
 __device__ __forceinline__ v16f sign_mfma(const v4i &a, const v4i &b, const v16f &c) {
     const v8i A = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
@@ -120,14 +133,17 @@ __device__ __forceinline__ v16f sign_mfma(const v4i &a, const v4i &b, const v16f
 }
 
 // MODE 0 = bound pass, 1 = collect pass.  One wave = one tile of 32 queries (16 query-fragment registers per 32 bits
-// of code); CAP = slots of a lane's candidate column in LDS (compacted beyond CAP - 16 entries, k <= CAP - 16).
+// of code).  Per-tile work besides the MFMAs is ~11 vector instructions (this file is compiled with -fno-honor-nans:
+// every value is an integer held in f32, so the maxima are bare v_max3_f32 without sNaN-quieting copies): the maximum of a
+// lane's 16 dots as a two-level tree and one compare; everything else happens only when some lane of the wave has a hit.
 template <int KS, int MODE, int KM>
 __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int IT = EntryTiles<KS>::value;
     constexpr int TILE_BYTES = KS * 1024;
     constexpr int ENTRY_BYTES = IT * TILE_BYTES;           // one ring entry = IT consecutive item tiles
     constexpr int PIECES = IT * KS;                        // 1 KiB LDS-DMA pieces per entry
-    constexpr int PPW = (PIECES + WAVES - 1) / WAVES;      // pieces per wave and entry
+    constexpr int PPW = (PIECES + WAVES - 1) / WAVES;      // pieces per wave and entry (a wave issues PPW or none)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -161,7 +177,8 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
 
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);       // low half of the flat address = LDS offset
     // entry e of this slice = tiles t0 + IT e .. + IT - 1 = PIECES consecutive 1 KiB pieces of the plane table
-    auto prefetch = [&](int e, int buf) {
+    auto prefetch = [&](int e) __attribute__((always_inline)) {
+        const int buf = e & (NBUF - 1);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int p = wv + WAVES * i;
@@ -171,12 +188,21 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
     };
 
     // ---- per-lane state ----
+    const int CAP = a.cap;
     uint32_t *cand = reinterpret_cast<uint32_t *>(smem + NBUF * ENTRY_BYTES) + wv * (CAP * 64);  // [slot][lane]
     int cnt = 0;
-    float thr = 3.0e38f;                                    // admit iff dot >= thr (dots are integers held in f32)
+    // Collect pass: the accumulators start at BIAS + r / 16 instead of 0 (r = register = row of the lane's 16), so an element
+    // is v = BIAS + dot + r / 16: exact in f32 (|dot| <= 512, 4 fraction bits, v in [2560, 3585) = one binade), ordered by
+    // (dot, r), and the maximum of a lane's 16 elements names its row: bits 12.. of the mantissa hold 1024 + dot, bits 8..11
+    // r.  dot >= t  <=>  v >= BIAS + t for integers, so thresholds live in the same domain.
+    constexpr float BIAS = 3072.0f;
+    float thr = 3.0e38f;                                    // admit iff v >= thr
     float best[KM];                                         // bound pass: KM largest group maxima of the dot, descending
+    v16f cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = MODE == 1 ? BIAS + (float)r * 0.0625f : 0.f;
     if (MODE == 1) {
-        if (q_ok) thr = (float)(a.nbits - 2 * a.thr0[q]);
+        if (q_ok && !(PS_HM_DEBUG & 64)) thr = BIAS + (float)(a.nbits - 2 * a.thr0[q]);     // 64: nothing passes (the usual exit only)
     } else {
 #pragma unroll
         for (int j = 0; j < KM; ++j) best[j] = NO_DOT;
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
 
     // a lane's column -> its k best keys in slots 0..k-1 (ascending), cnt = min(cnt, k); threshold tightened when the
     // column holds k keys: a later item (larger id) that only ties the k-th distance can never displace it
-    auto compact = [&]() {
+    auto compact = [&]() __attribute__((always_inline)) {
         const int k = a.k;
         for (int p = 0; p < k; ++p) {
             uint32_t bestk = (p < cnt) ? cand[p * 64 + lane] : EMPTY_KEY;
@@ -202,25 +228,37 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
         cnt = cnt < k ? cnt : k;
         if (cnt == k) {
             const int hk = (int)(cand[(k - 1) * 64 + lane] >> a.shift);
-            const float nthr = (float)(a.nbits - 2 * hk + 2);
+            const float nthr = BIAS + (float)(a.nbits - 2 * hk + 2);
             thr = nthr > thr ? nthr : thr;
         }
     };
 
-    auto epilogue = [&](v16f acc, int i) {
+    // acc is read in place (no copies): the usual exit is 8 + 3 maxima, one compare, one scalar branch
+    const int ham_c = a.nbits + 1024;
+    auto append_bits = [&](uint32_t bits, uint32_t row_base) __attribute__((always_inline)) {            // one element -> key in the lane's column
+        const uint32_t ham = (uint32_t)(ham_c - (int)((bits >> 12) & 0x7ffu)) >> 1;
+        const uint32_t r = (bits >> 8) & 15u;
+        cand[cnt * 64 + lane] = (ham << a.shift) | (row_base + (r & 3u) + 8u * (r >> 2));
+        ++cnt;
+    };
+    auto epilogue = [&](v16f &acc, int i) __attribute__((always_inline)) {
         const int64_t t = t0 + i;
-        if (t >= last_tile) {                               // wave-uniform: mask the padding rows of the table's end
-            const int64_t left = a.N - t * 32;              // valid rows of this tile (<= 0: a padding tile of the last entry)
+        if (t >= last_tile) {                               // wave-uniform, once per table: mask the padding rows of its end
+            const int64_t left64 = a.N - t * 32;            // valid rows of this tile (<= 0: a padding tile of the last entry)
+            const int left = (int)(left64 < 0 ? 0 : left64 > 32 ? 32 : left64) - 4 * lh;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if ((r & 3) + 8 * (r >> 2) + 4 * lh >= left) acc[r] = NO_DOT;
+                if ((r & 3) + 8 * (r >> 2) >= left) acc[r] = MODE == 1 ? 0.f : NO_DOT;
         }
-        // maximum of the lane's 16 dots as a two-level tree: the four group maxima localise a hit
+        // maximum of the lane's 16 elements as a tree over the four groups of consecutive registers
         float g[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] = fmaxf(fmaxf(fmaxf(acc[4 * j], acc[4 * j + 1]), acc[4 * j + 2]), acc[4 * j + 3]);
-        const float m = fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), g[3]);
         if (MODE == 0) {
+            const float m = fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), g[3]);
+            // a lane's list changes only when its new group maximum beats the list's last entry: after the first few
+            // tiles that is rare, and the insertion network (2 KM instructions) runs for the whole wave only then
+            if (__ballot(m > best[KM - 1]) == 0ull) return;
             float x = m;
 #pragma unroll
             for (int j = 0; j < KM; ++j) {
@@ -230,109 +268,121 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
             }
             return;
         }
-        if (__ballot(m >= thr) == 0ull) return;             // the usual exit
+        const float m01 = fmaxf(g[0], g[1]), m23 = fmaxf(g[2], g[3]);
+        const float m = fmaxf(m01, m23);
+        PS_HM_COUNT(0, 1);
+        if (__ballot(m >= thr) == 0ull) return;             // the usual exit (~1/3 of the tiles at 10 000 x 59 047 x 512 bit)
+        PS_HM_COUNT(1, 1);
+        // Some lane holds an element >= thr: about one per 1 000 elements, i.e. usually ONE row of ONE lane of the wave's
+        // 64 x 16.  Every scalar branch on a vector compare costs this wave a round trip that its SIMD partner's MFMA stream
+        // does not hide (the r02 version walked groups and rows with ~12 such branches: ~900 cycles per entry, 2/3 of the
+        // collect pass), so the common case is straight-line: the maximum itself names its row (fraction bits) and is
+        // appended; that is complete unless a second element of the lane passes too.  Two distinct rows differ in r >> 2 or
+        // in r & 3, so a second hit exists iff the second-largest maximum over the groups {4 j ..} (g) or over the groups
+        // {j, 4 + j, 8 + j, 12 + j} (h) passes: 20 more vector instructions, one branch, and only then the walk over all rows.
+        const float sg = fmaxf(fmaxf(fminf(m01, m23), fminf(g[0], g[1])), fminf(g[2], g[3]));
+        float h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = fmaxf(fmaxf(fmaxf(acc[j], acc[4 + j]), acc[8 + j]), acc[12 + j]);
+        const float h01 = fmaxf(h[0], h[1]), h23 = fmaxf(h[2], h[3]);
+        const float sh = fmaxf(fmaxf(fminf(h01, h23), fminf(h[0], h[1])), fminf(h[2], h[3]));
         const uint32_t base = (uint32_t)i * 32u + 4u * lh;
+        if (__ballot(fmaxf(sg, sh) >= thr) == 0ull) {
+            if (m >= thr) append_bits(__float_as_uint(m), base);
+        } else {
+            PS_HM_COUNT(2, 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (__ballot(g[j] >= thr) == 0ull) continue;    // rows 8 j + 4 lh + 0..3
-#pragma unroll
-            for (int r = 4 * j; r < 4 * j + 4; ++r) {
-                const bool hit = acc[r] >= thr;
-                if (__ballot(hit) != 0ull) {
-                    if (hit) {
-                        const uint32_t ham = (uint32_t)(a.nbits - (int)acc[r]) >> 1;
-                        cand[cnt * 64 + lane] = (ham << a.shift) | (base + (r & 3) + 8 * (r >> 2));
-                        ++cnt;
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r)
+                if (acc[r] >= thr) append_bits(__float_as_uint(acc[r]), base);
         }
-        if (__ballot(cnt > CAP - 16) != 0ull) compact();    // room for one more tile (16 rows per lane) is guaranteed
+        if (__ballot(cnt > CAP - 16) != 0ull) { PS_HM_COUNT(5, 1); compact(); }   // room for one more tile (16 rows per lane) is guaranteed
     };
 
-    // ---- sweep: ring of NBUF item tiles, one barrier per tile ----
-    // History on MI355X (10 000 x 59 047 x 512 bit, k = 11): int8 signs (v_mfma_i32_32x32x32_i8), one tile per barrier:
-    // collect 338 us + bound 58 us; fp4 signs (half the MFMAs, half the bytes): 281 + 45; two tiles per barrier (two
-    // independent accumulation chains, half the barriers): 262 + 45 = 0.33 ms for the whole call, popcount kernel 0.71 ms.
-    // Measured alternatives that were NOT faster (int8 version, collect pass 338 us + bound pass 58 us):
-    //  * 2 query tiles per wave (each LDS fragment feeds two MFMAs; 250 VGPRs, candidate columns in global memory): 561 us
-    //    -- with the sweep's matrix work alone (no epilogue) 222 us vs 233 us: the LDS reads were never the limit;
-    //  * the two waves of a SIMD half a tile apart (one multiplies while the other reads fragments), with one and with
-    //    two accumulation chains per wave: 381 / 399 us -- the matrix loop alone 253 / 227 us;
-    //  * a shared per-query histogram of admitted candidates (atomics + L1-bypassing re-reads every 8 tiles) that lets
-    //    every lane tighten its threshold during the sweep: the candidates per query drop 3x and the bound pass can
-    //    shrink to 2.5 % of the table, but the histogram's own memory operations sit in the ring's counted vmcnt
-    //    waits: 383 - 399 us + 34 us, the same total;
-    //  * the matrix loop alone on constant codes: 174 us vs 204 us on random codes on the same box (and 204 - 233 us
-    //    between boxes): the loop runs at the clock the chip holds under int8 MFMA load (SQ_VALU_MFMA_BUSY_CYCLES =
-    //    32 cycles x the 9.45 M MFMAs of a sweep = 295 K cycles per SIMD, i.e. 123 us at the 2.4 GHz the peak is quoted at).
-    // query fragments / bounds are in: nothing of the compiler's is in flight from here on.  The builtin form, so that
+    // ---- sweep ----
+    // Ring of NBUF entries in LDS (filled by LDS-DMA, every wave 1/8 of an entry), two register sets of item fragments:
+    // while the MFMAs of entry i run from one set, the ds_read_b128s of entry i + 1 fill the other, so the LDS round trip
+    // (all 8 waves read the whole entry: 128 KiB per entry and CU = half of the LDS bandwidth over an entry's MFMA time)
+    // is under the matrix work instead of in front of it (r02: reads, then MFMAs, every entry: the sweep without any
+    // epilogue took 2 200 cycles per entry against 1 024 of MFMA issue per SIMD).  Waves 4-7 run the epilogue of entry
+    // i - 1 BEFORE the MFMAs of entry i (on the same accumulator registers, no copy), waves 0-3 after them, so the two
+    // waves of a SIMD alternate between the matrix pipe and the VALU instead of meeting at both.
+    // History on MI355X (10 000 x 59 047 x 512 bit, k = 11): int8 signs, one tile per barrier: collect 338 us + bound 58 us;
+    // fp4 signs: 281 + 45; two tiles per barrier: 262 + 45 (r02, 0.32 ms for the call; popcount kernel 0.71 ms).
+    // Measured alternatives that were NOT faster (int8 version): 2 query tiles per wave (250 VGPRs, candidate columns in
+    // global memory): 561 us; SIMD partners half a tile apart: 381 / 399 us; a shared per-query histogram of admitted
+    // candidates that tightens thresholds during the sweep: same total (its memory operations sit in the ring's waits).
+    // Query fragments / bounds are in: nothing of the compiler's is in flight from here on.  The builtin form, so that
     // hipcc's own wait-count pass knows it (an asm wait is invisible to it and it would wait vmcnt(0) again at the
     // first use of a query fragment INSIDE the loop, i.e. drain the ring on every tile)
     __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
 #pragma unroll
     for (int j = 0; j < NBUF - 1; ++j)
-        if (j < nt) prefetch(j, j);
-    v16f acc_prev[IT];
+        if (j < nt) prefetch(j);
+    v4i avA[IT][KS], avB[IT][KS];
+    v16f acc[IT];
 #pragma unroll
     for (int u = 0; u < IT; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc_prev[u][r] = NO_DOT;
-    int buf = 0;
-    for (int i = 0; i < nt; ++i) {
-        // own pieces of entry i have landed (younger entries' may be in flight); after the barrier everybody's have, and
-        // everybody has finished reading entry i-1, whose buffer the next LDS-DMA overwrites
-        const int younger = nt - 1 - i;
-        if (younger >= NBUF - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NBUF - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(PS_HM_DEBUG & 4)) __builtin_amdgcn_s_barrier();
-        if (i + NBUF - 1 < nt) prefetch(i + NBUF - 1, buf >= 1 ? buf - 1 : NBUF - 1);
-        // all item fragments of the entry are requested at once (IT * KS ds_read_b128 in flight; with the compiler's own
-        // 2-deep interleave the LDS round trip sat between every MFMA pair); a late wave's previous-entry epilogue runs
-        // under that latency.  The IT tiles are IT independent accumulation chains.
-        const unsigned char *tb = smem + buf * ENTRY_BYTES + lane * 16;
-        v4i av[IT][KS];
+        for (int r = 0; r < 16; ++r) acc[u][r] = NO_DOT;
+
+    auto read_entry = [&](int e, v4i (&av)[IT][KS]) __attribute__((always_inline)) {
+        const unsigned char *tb = smem + (e & (NBUF - 1)) * ENTRY_BYTES + lane * 16;
 #pragma unroll
         for (int u = 0; u < IT; ++u)
 #pragma unroll
             for (int s = 0; s < KS; ++s)
-                av[u][s] = (PS_HM_DEBUG & 16) ? v4i{i, s, lane, u} : *reinterpret_cast<const v4i *>(tb + (u * KS + s) * 1024);
-        __builtin_amdgcn_sched_group_barrier(0x100, IT * KS, 0);
+                av[u][s] = (PS_HM_DEBUG & 16) ? v4i{e, s, lane, u} : *reinterpret_cast<const v4i *>(tb + (u * KS + s) * 1024);
+    };
+    // own pieces of entry e have landed when at most `younger` younger entries' pieces are outstanding
+    auto wait_entry = [&](int e) __attribute__((always_inline)) {
+        const int younger = nt - 1 - e;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 2) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto step = [&](int i, v4i (&cur)[IT][KS], v4i (&nxt)[IT][KS]) __attribute__((always_inline)) {
+        // entry i + 1: own pieces landed; after the barrier everybody's have, and everybody has finished the MFMAs of entry
+        // i - 1, i.e. has entry i in registers and is done with the buffer of entry i - 1, which the next LDS-DMA overwrites
+        if (i + 1 < nt) wait_entry(i + 1);
+        if (!(PS_HM_DEBUG & 4)) __builtin_amdgcn_s_barrier();
+        if (i + NBUF - 1 < nt) prefetch(i + NBUF - 1);
+        if (i + 1 < nt) read_entry(i + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
         if (late && i > 0 && !(PS_HM_DEBUG & 1)) {
+            if (PS_HM_DEBUG & 128) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-            for (int u = 0; u < IT; ++u) epilogue(acc_prev[u], (i - 1) * IT + u);
+            for (int u = 0; u < IT; ++u) epilogue(acc[u], (i - 1) * IT + u);
+            if (PS_HM_DEBUG & 128) __builtin_amdgcn_s_setprio(0);
         }
-        v16f acc[IT];
-#pragma unroll
-        for (int u = 0; u < IT; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int u = 0; u < IT; ++u) {
-                if (PS_HM_DEBUG & 8) acc[u][s & 15] += (float)(av[u][s][0] ^ bq[s][1]);
-                else acc[u] = sign_mfma(av[u][s], bq[s], acc[u]);
+                const v16f c = s == 0 ? cinit : acc[u];
+                if (PS_HM_DEBUG & 8) acc[u][s & 15] += (float)(cur[u][s][0] ^ bq[s][1]);
+                else acc[u] = sign_mfma(cur[u][s], bq[s], c);
             }
-        if (PS_HM_DEBUG & 1) {
-#pragma unroll
-            for (int u = 0; u < IT; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc_prev[0][r] += acc[u][r];     // keep the work alive
-        } else if (!late) {
+        if (!late && !(PS_HM_DEBUG & 1)) {
+            if (PS_HM_DEBUG & 128) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int u = 0; u < IT; ++u) epilogue(acc[u], i * IT + u);
-        } else {
-#pragma unroll
-            for (int u = 0; u < IT; ++u) acc_prev[u] = acc[u];
+            if (PS_HM_DEBUG & 128) __builtin_amdgcn_s_setprio(0);
         }
-        buf = buf + 1 < NBUF ? buf + 1 : 0;
+    };
+    if (nt > 0) {
+        wait_entry(0);
+        if (!(PS_HM_DEBUG & 4)) __builtin_amdgcn_s_barrier();
+        read_entry(0, avA);
+    }
+    for (int i = 0; i < nt; i += 2) {
+        step(i, avA, avB);
+        if (i + 1 < nt) step(i + 1, avB, avA);
     }
     if (late && nt > 0 && !(PS_HM_DEBUG & 1)) {
 #pragma unroll
-        for (int u = 0; u < IT; ++u) epilogue(acc_prev[u], (nt - 1) * IT + u);
+        for (int u = 0; u < IT; ++u) epilogue(acc[u], (nt - 1) * IT + u);
     }
-    if (PS_HM_DEBUG & 1) { if (max16(acc_prev[0]) == 12345678.f) cnt = 1; }
+    if (PS_HM_DEBUG & 1) { if (acc[0][0] + acc[IT - 1][5] == 12345678.f) cnt = 1; }
 
     // ---- results ----
     if (MODE == 0) {
@@ -481,7 +531,7 @@ int key_shift_bits(int nbits) {
 
 struct Plan {
     bool ok;
-    int KS, nqb, slices, bslices, shift, km;
+    int KS, IT, nqb, slices, bslices, shift, km, cap;
     int64_t tiles, tiles_per_slice, sample_tiles, btiles_per_slice;
     size_t off_thr, off_bl, off_i, off_d, total;
 };
@@ -500,7 +550,9 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     if (!(p.KS == 1 || p.KS == 2 || p.KS == 4 || p.KS == 8)) return p;
     if (k <= 0 || k > 32) return p;
     if (nq < 64 || N < 4096) return p;                    // small problems: the popcount kernel has no tile padding
-    p.km = k <= 16 ? 16 : 32;
+    const int IT = p.KS >= 4 ? 2 : 4;                      // EntryTiles<KS>
+    p.IT = IT;
+    p.cap = k <= 16 ? 32 : 48;                             // a lane's column: k kept + one tile's 16 rows
     p.shift = key_shift_bits(cs * 8);
     p.tiles = (N + 31) >> 5;
     const int64_t nqt = (nq + 31) >> 5;
@@ -524,10 +576,13 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     if (st > p.tiles) st = p.tiles;
     int64_t bs = slots / p.nqb;
     if (bs < 1) bs = 1;
-    if (bs > 512 / p.km) bs = 512 / p.km;                  // <= 2 bs lists of KM values per query (bound_select: 1024)
+    if (bs > 16) bs = 16;                                  // <= 2 bs lists of KM <= 32 values per query (bound_select: 1024)
     while (bs > 1 && st / bs < 16) --bs;
+    // values a lane keeps: 2 bs lanes see a query's sample; with >= 3 k values among them four per lane are enough for the
+    // k-th smallest to be (nearly always) the true one, and ANY k distinct groups give a valid bound
     p.btiles_per_slice = ((st + bs - 1) / bs + IT - 1) / IT * IT;
     p.bslices = (int)((st + p.btiles_per_slice - 1) / p.btiles_per_slice);
+    p.km = (2 * p.bslices * 4 >= 3 * k) ? 4 : (k <= 16 ? 16 : 32);
     p.sample_tiles = st;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
@@ -549,25 +604,28 @@ bool allow_lds(K kernel, size_t bytes) {
 
 template <int KS>
 int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t *bl, int64_t nq) {
+    constexpr int IT = EntryTiles<KS>::value;
     const size_t tiles_lds = (size_t)NBUF * IT * KS * 1024;
-    const size_t lds = tiles_lds + (size_t)WAVES * CAP * 64 * sizeof(uint32_t);
+    const size_t lds = tiles_lds + (size_t)WAVES * p.cap * 64 * sizeof(uint32_t);
     // once per (kernel, device): one process may drive several GPUs
     static bool lds_done[64] = {};
     int devid = 0;
     if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PS_ELAUNCH;
     bool lds_ok = lds_done[devid];
     if (!lds_ok) {
-        lds_ok = allow_lds(hamming_mfma_kernel<KS, 0, 16>, 160 * 1024) && allow_lds(hamming_mfma_kernel<KS, 0, 32>, 160 * 1024) &&
-                 allow_lds(hamming_mfma_kernel<KS, 1, 16>, 160 * 1024);
+        lds_ok = allow_lds(hamming_mfma_kernel<KS, 0, 4>, 160 * 1024) && allow_lds(hamming_mfma_kernel<KS, 0, 16>, 160 * 1024) &&
+                 allow_lds(hamming_mfma_kernel<KS, 0, 32>, 160 * 1024) && allow_lds(hamming_mfma_kernel<KS, 1, 4>, 160 * 1024);
         lds_done[devid] = lds_ok;
     }
     if (!lds_ok) return PS_ELAUNCH;
     a.nqb = p.nqb;
+    a.cap = p.cap;
     // bound
     HArgs b = a;
     b.tile_begin = 0; b.tile_end = p.sample_tiles; b.tiles_per_slice = p.btiles_per_slice; b.slices = p.bslices; b.bl = bl;
     const unsigned gb = (unsigned)(p.nqb * p.bslices);
-    if (p.km == 16) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 16>), dim3(gb), dim3(512), tiles_lds, st, b);
+    if (p.km == 4) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 4>), dim3(gb), dim3(512), tiles_lds, st, b);
+    else if (p.km == 16) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 16>), dim3(gb), dim3(512), tiles_lds, st, b);
     else hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 32>), dim3(gb), dim3(512), tiles_lds, st, b);
     PS_CHECK_LAUNCH();
     int64_t gs = ps_cdiv(nq, 4);
@@ -578,7 +636,7 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
     a.tile_begin = 0; a.tile_end = p.tiles; a.tiles_per_slice = p.tiles_per_slice; a.slices = p.slices; a.thr0 = thr0;
     a.list_base = 0;
     const unsigned gc = (unsigned)(p.nqb * p.slices);
-    hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 16>), dim3(gc), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 4>), dim3(gc), dim3(512), lds, st, a);
     PS_CHECK_LAUNCH();
     return PS_OK;
 }
@@ -587,7 +645,7 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
 
 extern "C" size_t ps_lsh_planes_bytes(int64_t n, int cs) {
     if (n <= 0 || cs <= 0 || cs % 8 != 0) return 0;
-    return (size_t)(((n + 31) / 32 + IT - 1) / IT * IT) * (size_t)(cs / 8) * 1024;        // whole ring entries
+    return (size_t)(((n + 31) / 32 + PAD_TILES - 1) / PAD_TILES * PAD_TILES) * (size_t)(cs / 8) * 1024;   // whole ring entries
 }
 
 extern "C" int ps_lsh_expand(const uint8_t *codes, int64_t n, int cs, void *planes, ps_stream_t stream) {
@@ -597,7 +655,7 @@ extern "C" int ps_lsh_expand(const uint8_t *codes, int64_t n, int cs, void *plan
     if (!codes || !planes || reinterpret_cast<size_t>(codes) % 4 != 0 || reinterpret_cast<size_t>(planes) % 16 != 0)
         return PS_EINVAL;
     const int KS = cs / 8;
-    const int64_t pieces = (((n + 31) / 32 + IT - 1) / IT * IT) * KS * 64;                  // padding tiles are zero-filled
+    const int64_t pieces = (((n + 31) / 32 + PAD_TILES - 1) / PAD_TILES * PAD_TILES) * KS * 64;   // padding tiles are zero-filled
     int64_t grid = ps_cdiv(pieces, 256);
     if (grid > 256 * 64) grid = 256 * 64;
     hipLaunchKernelGGL(lsh_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ps_stream(stream),

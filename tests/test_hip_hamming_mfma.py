@@ -37,7 +37,7 @@ def test_sign_planes_layout():
     n, cs = 77, 16
     codes = rs.randint(0, 256, size=(n, cs)).astype(np.uint8)
     pl = dense.lsh_expand(torch.from_numpy(codes).cuda()).cpu().numpy()
-    KS, tiles = cs // 8, ((n + 31) // 32 + 1) // 2 * 2            # padded to whole ring entries of two tiles
+    KS, tiles = cs // 8, ((n + 31) // 32 + 3) // 4 * 4            # padded to whole ring entries (2 or 4 tiles)
     assert pl.size == tiles * KS * 1024
     nib = np.stack([pl & 15, pl >> 4], axis=-1).reshape(tiles, KS, 64, 32)          # low nibble first
     bits = np.unpackbits(codes, axis=1, bitorder="little")      # bit j of the code, LSB-first bytes (faiss)
