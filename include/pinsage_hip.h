@@ -233,6 +233,18 @@ int ps_l2_topk(const float *X, int64_t N, int D, const float *Q, int64_t nq, int
                const uint32_t *probe, int words, float *dist, int64_t *ids, void *workspace,
                size_t workspace_bytes, ps_stream_t stream);
 
+/* The inverted-file form of the same scan (faiss.IndexIVFFlat, utils/nearest_neighbors.py:88-93; nprobe = min(nlist, 20), :134):
+ * X float[N,D] holds the items SORTED BY LIST (list l = rows [list_ptr[l], list_ptr[l+1]), list_ptr int64[nlist+1]),
+ * max_list = the longest list, item_ids int64[N] = the original id of every sorted row, probes int32[nq, nprobe] = the lists
+ * each query visits (entries outside [0, nlist) are skipped).  The (query, list) pairs are grouped by list on the device,
+ * one grouped fp32-MFMA product multiplies every list's queries with that list's rows only, and a query's top-k sweeps its
+ * nprobe result rows: nq * nprobe * (list length) dot products instead of nq * N.  Same arithmetic per (query, item) as
+ * ps_l2_topk: identical (dist, ids) to the masked form. */
+size_t ps_ivf_topk_workspace_bytes(int64_t nq, int64_t N, int D, int k, int nlist, int nprobe, int64_t max_list);
+int ps_ivf_topk(const float *X, int64_t N, int D, const int64_t *list_ptr, int nlist, int64_t max_list,
+                const int64_t *item_ids, const float *Q, int64_t nq, const int32_t *probes, int nprobe, int k,
+                float *dist, int64_t *ids, void *workspace, size_t workspace_bytes, ps_stream_t stream);
+
 /* ---- next row: the aggregation of GraphConv.propagate (model/pinsage.py:53-54, 70-92; PyG
  * MessagePassing, aggr='add', flow source->target): out[r] = sum over the edges e of CSR row r of val[e] * x[col[e]].
  * rowptr int64[V+1] / col int32[E] = edges grouped by TARGET node (ps_csr_build with the edge_index rows swapped),

@@ -57,6 +57,7 @@ struct GemmArgs {
     const float *bias; int N; int flags;
     float *y;            // EPI 0
     uint8_t *codes; int cs;  // EPI 1
+    const int64_t *grp;      // optional (grouped products, psi_linear_grouped): per 64-row block (W row offset, columns, y offset)
 };
 
 // 8 consecutive k of one row (zero-filled outside [0,K) / invalid row)
@@ -144,7 +145,8 @@ template <int WM, int WN, int TM, int TN, int BK, int EPI, bool FAST>
 #ifndef PS_GEMM_OCC
 #define PS_GEMM_OCC 2      // two blocks per CU (<= 256 VGPR + AGPR): one block's barriers and epilogue under the other's MFMAs
 #endif
-__global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(GemmArgs g_in) {
+    GemmArgs g = g_in;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     // global loads of the next K step spread over the MFMAs (below): pays for the 2 x 2-tile waves (10 loads per 64 MFMAs);
     // the 1 x 2-tile blocks measured 3 % slower with it (LSH projection 0.151 -> 0.155 ms)
@@ -160,6 +162,16 @@ __global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(Gem
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int li = lane & 31, lh = lane >> 5;
+    // grouped products (the inverted-file scan, csrc/dot_topk.hip): row block blockIdx.x multiplies its 64 rows of x with ITS
+    // OWN block of W rows -- the items of one inverted list -- and writes a compact [rows, columns] slab
+    if (g.grp != nullptr) {
+        const int64_t *d = g.grp + (size_t)blockIdx.x * 3;
+        const int64_t w_row0 = d[0], ncols = d[1], y_off = d[2];
+        if (n0 >= ncols) return;                                       // block-uniform
+        g.W += w_row0 * g.ldw;
+        g.N = (int)ncols;
+        g.y += y_off - m0 * ncols;                                     // y[(m0 + r) * N + c] = slab[r * ncols + c]
+    }
 
 #if PS_GEMM_DEBUG & 64
     if (lane == 0 && blockIdx.x < 4096) {
@@ -734,6 +746,23 @@ int launch_gemm(const GemmArgs &g, hipStream_t st) {
 }
 
 }  // namespace
+
+// Grouped x W^T: row block b (64 rows of x, M a multiple of 64) is multiplied with W rows [grp[3b], grp[3b] + grp[3b+1]) and its
+// [64, grp[3b+1]] result written at y + grp[3b+2] (row stride grp[3b+1]); max_cols = the largest grp[3b+1].  Same k-ordered fp32
+// chain per output as ps_linear.  Internal to the library (ps_ivf_topk).
+int psi_linear_grouped(const float *x, int64_t M, int K, const float *W, int ldw, float *y, const int64_t *grp, int max_cols,
+                       ps_stream_t stream) {
+    if (M <= 0 || M % 64 != 0 || K <= 0 || max_cols <= 0 || !x || !W || !y || !grp || ldw < K) return PS_EINVAL;
+    GemmArgs g{x, M, K, W, ldw, nullptr, 0, nullptr, 0, nullptr, max_cols, 0, y, nullptr, 0, grp};
+    hipStream_t st = ps_stream(stream);
+    dim3 grid((unsigned)(M / 64), (unsigned)ps_cdiv(max_cols, 128));
+    if (aligned_operand(x, K, K) && aligned_operand(W, K, ldw))
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, 0, true>), grid, dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 2, 32, 0, false>), grid, dim3(256), 0, st, g);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
 
 extern "C" int ps_linear(const float *x, int64_t M, int K, const float *W, int ldw, const float *b, int N,
                          const float *x2, int K2, const float *W2, int ldw2, int flags, float *y, ps_stream_t stream) {

@@ -16,6 +16,10 @@ static inline hipStream_t ps_stream(ps_stream_t s) { return reinterpret_cast<hip
 
 static inline int64_t ps_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// internal (not part of the C ABI): grouped x W^T of csrc/dense_mfma.hip, used by the inverted-file scan
+int psi_linear_grouped(const float *x, int64_t M, int K, const float *W, int ldw, float *y, const int64_t *grp, int max_cols,
+                       ps_stream_t stream);
+
 __device__ __forceinline__ int ps_lane() { return threadIdx.x & 63; }
 
 // All LDS traffic of a wave is issued in order; this makes earlier LDS writes/atomics of the

@@ -245,6 +245,35 @@ def l2_topk(X, Q, k, assign=None, probe=None):
     return dist, ids
 
 
+def ivf_topk(Xs, list_ptr, item_ids, Q, probes, k, max_list=None):
+    """Inverted-file scan (ps_ivf_topk): Xs fp32 [N, D] sorted by list, list_ptr int64 [nlist + 1], item_ids int64 [N] (original
+    id of every sorted row), probes int32 [nq, nprobe] -> (dist fp32 [nq, k], ids int64 [nq, k]) by (squared L2, original id).
+    max_list = the longest list (computed here with one host sync when not given: an index knows it from `add`)."""
+    Xs = Xs.contiguous()
+    Q = Q.to(Xs.device).contiguous()
+    probes = probes.to(device=Xs.device, dtype=torch.int32).contiguous()
+    list_ptr = list_ptr.to(device=Xs.device, dtype=torch.int64).contiguous()
+    item_ids = item_ids.to(device=Xs.device, dtype=torch.int64).contiguous()
+    N, D = int(Xs.size(0)), int(Xs.size(1))
+    nq, nprobe, nlist = int(Q.size(0)), int(probes.size(1)), int(list_ptr.numel()) - 1
+    if k < 1:
+        raise ValueError(f"k must be positive, got {k}")
+    if int(probes.size(0)) != nq or int(item_ids.numel()) != N or int(Q.size(1)) != D:
+        raise ValueError("shape mismatch")
+    if max_list is None:
+        max_list = int((list_ptr[1:] - list_ptr[:-1]).max().item()) if nlist else 0
+    dist = torch.empty((nq, k), dtype=torch.float32, device=Xs.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=Xs.device)
+    L = nv.lib()
+    wsb = int(L.ps_ivf_topk_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(D), nv.i32(k), nv.i32(nlist), nv.i32(nprobe), nv.i64(int(max_list))))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=Xs.device)
+    with torch.cuda.device(Xs.device):
+        nv.call("ps_ivf_topk", nv.ptr(Xs), nv.i64(N), nv.i32(D), nv.ptr(list_ptr), nv.i32(nlist), nv.i64(int(max_list)), nv.ptr(item_ids),
+                nv.ptr(Q), nv.i64(nq), nv.ptr(probes), nv.i32(nprobe), nv.i32(int(k)), nv.ptr(dist), nv.ptr(ids), nv.ptr(ws),
+                nv.C.c_size_t(wsb), nv.stream())
+    return dist, ids
+
+
 _jump_polys_dev = {}
 
 

@@ -33,7 +33,7 @@ SYMBOLS = [
     "ps_guide_build", "ps_pack_edges", "ps_bucket_build", "ps_graph_stats", "ps_walk_sample", "ps_walk_sample_layers", "ps_walk_paths", "ps_uniform_offsets", "ps_mt19937_workspace_bytes", "ps_mt19937_chunk_log2", "ps_mt19937_random_sample", "ps_mt19937_raw_stream",
     "ps_importance_pool", "ps_linear", "ps_lsh_encode", "ps_hamming_topk_workspace_bytes", "ps_hamming_topk",
     "ps_lsh_planes_bytes", "ps_lsh_expand", "ps_hamming_topk_mfma_workspace_bytes", "ps_hamming_topk_mfma",
-    "ps_topk_merge", "ps_topk_merge_strided", "ps_dot_topk_workspace_bytes", "ps_dot_topk", "ps_l2_topk_workspace_bytes", "ps_l2_topk", "ps_spmm_csr",
+    "ps_topk_merge", "ps_topk_merge_strided", "ps_dot_topk_workspace_bytes", "ps_dot_topk", "ps_l2_topk_workspace_bytes", "ps_l2_topk", "ps_ivf_topk_workspace_bytes", "ps_ivf_topk", "ps_spmm_csr",
 ]
 
 
@@ -51,7 +51,7 @@ def lib():
         _lib = C.CDLL(SO_PATH)
         _lib.ps_error_string.restype = C.c_char_p
         for name in ("ps_csr_build_workspace_bytes", "ps_hamming_topk_workspace_bytes", "ps_dot_topk_workspace_bytes",
-                     "ps_l2_topk_workspace_bytes", "ps_mt19937_workspace_bytes", "ps_lsh_planes_bytes",
+                     "ps_l2_topk_workspace_bytes", "ps_ivf_topk_workspace_bytes", "ps_mt19937_workspace_bytes", "ps_lsh_planes_bytes",
                      "ps_hamming_topk_mfma_workspace_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_size_t

@@ -163,3 +163,86 @@ def test_exact_and_l2_search_any_k(k):
         best = np.sort(sim[r])[::-1][kk - 1]
         assert np.all(sim[r, ii[r, :kk]] >= best - 1e-5)
         assert np.all(np.diff(vals[r, :kk]) <= 1e-6)                                 # descending
+
+
+def test_inverted_file_scan_equals_masked_scan():
+    """ps_ivf_topk (items sorted by list, only the probed lists' row blocks multiplied and swept) vs the masked full product
+    (ps_l2_topk with assign / probe) and the fp64 numpy restatement: identical ids, identical fp32 distances; ragged and
+    EMPTY lists, a list larger than a column tile, k below / above the items a query sees, queries in arbitrary order."""
+    from pinsage_hip import dense
+    rs = np.random.RandomState(17)
+    N, D, nq, nlist, nprobe = 5000, 40, 333, 41, 6
+    X = rs.standard_normal((N, D)).astype(np.float32)
+    X[100] = X[7]; X[4000] = X[7]                                                   # exact ties: broken by ORIGINAL id
+    Q = np.concatenate([X[:200] + 0.05 * rs.standard_normal((200, D)).astype(np.float32), rs.standard_normal((nq - 200, D)).astype(np.float32)])
+    Q[0] = X[7]
+    assign = rs.randint(0, nlist, size=N).astype(np.int32)
+    assign[assign == 13] = 12                                                       # list 13 is empty, list 12 large
+    assign[:700] = 5                                                                # > 128 x 5 items: spans several column tiles
+    assign[[7, 100, 4000]] = 5
+    probe_lists = np.stack([rs.permutation(nlist)[:nprobe] for _ in range(nq)]).astype(np.int32)
+    probe_lists[0, 0] = 5
+    probe_lists[1] = [13, 13, 13, 13, 13, 13]                                       # probes only the empty list -> all padding
+    order = np.argsort(assign, kind="stable")
+    list_ptr = np.zeros(nlist + 1, dtype=np.int64)
+    list_ptr[1:] = np.cumsum(np.bincount(assign, minlength=nlist))
+    Xd, Qd = torch.from_numpy(X).cuda(), torch.from_numpy(Q).cuda()
+    d2 = ((Q[:, None, :].astype(np.float64) - X[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    vis = (probe_lists[:, :, None] == assign[None, None, :]).any(axis=1)
+    for k in (1, 10, 40, 300):
+        di, ii = dense.ivf_topk(Xd[torch.from_numpy(order).cuda()], torch.from_numpy(list_ptr), torch.from_numpy(order), Qd,
+                                torch.from_numpy(probe_lists), k)
+        bits = _probe_bits(np.where(probe_lists == 13, 12, probe_lists) if False else probe_lists, nlist)
+        dm, im = dense.l2_topk(Xd, Qd, k, assign=torch.from_numpy(assign).cuda(), probe=torch.from_numpy(bits.view(np.int32)).cuda())
+        assert torch.equal(ii, im) and torch.equal(di, dm), k
+        ii = ii.cpu().numpy()
+        nvis = vis.sum(1)
+        want = np.argsort(np.where(vis, d2, np.inf), axis=1, kind="stable")[:, :k]
+        for r in range(nq):
+            kk = min(k, nvis[r])
+            assert np.all(ii[r, kk:] == -1)
+            if r == 0:                                                               # the three copies of X[7] tie at distance 0
+                assert ii[r, :3].tolist() == [7, 100, 4000] or k < 3
+        # fp32 vs fp64 order can differ only between near-ties; compare as sets with the distance bound
+        for r in range(0, nq, 7):
+            kk = min(k, nvis[r])
+            if kk:
+                assert np.all(d2[r, ii[r, :kk]] <= d2[r, want[r, kk - 1]] + 1e-3)
+    assert np.all(ii[1] == -1)
+
+
+def test_ivf_index_uses_the_inverted_file_and_is_3x_faster_than_flat():
+    """same ids as the masked search through the class, and at the reference's defaults (59 047 x 128,
+    10 000 queries, 100 lists, nprobe 20) the inverted-file search is >= 3x faster than the flat L2 search."""
+    import time
+    from utils.nearest_neighbors import WeakANDIndex, _DeviceFlatL2
+    g = torch.Generator().manual_seed(3)
+    M, D, nq, k = 59047, 128, 10000, 11
+    cent = torch.randn(300, D, generator=g)
+    emb = torch.nn.functional.normalize(cent[torch.randint(0, 300, (M,), generator=g)] + 0.35 * torch.randn(M, D, generator=g), dim=1).cuda()
+    idx = WeakANDIndex(D)
+    idx.build(emb)
+    idx.index.nprobe = 20
+    q = emb[torch.randperm(M, generator=g)[:nq].cuda()].contiguous()
+    d1, i1 = idx.index.search_device(q, k)
+    idx.index.masked = True
+    d2, i2 = idx.index.search_device(q, k)
+    idx.index.masked = False
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)
+    flat = _DeviceFlatL2(D)
+    flat.add(emb)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 10
+
+    t_ivf = timed(lambda: idx.index.search_device(q, k))
+    t_flat = timed(lambda: flat.search_device(q, k))
+    print(f"IVF (nlist 100, nprobe 20) {t_ivf * 1e3:.3f} ms, flat L2 {t_flat * 1e3:.3f} ms, x{t_flat / t_ivf:.2f}")
+    assert t_flat / t_ivf >= 3.0
