@@ -136,10 +136,16 @@ __device__ __forceinline__ v16f sign_mfma(const v4i &a, const v4i &b, const v16f
 // of code).  Per-tile work besides the MFMAs is ~11 vector instructions (this file is compiled with -fno-honor-nans:
 // every value is an integer held in f32, so the maxima are bare v_max3_f32 without sNaN-quieting copies): the maximum of a
 // lane's 16 dots as a two-level tree and one compare; everything else happens only when some lane of the wave has a hit.
-template <int KS, int MODE, int KM>
-__global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
+// DB = true : one workgroup per CU (two waves per SIMD), two register sets of item fragments (the LDS reads of entry i + 1 under
+//             the MFMAs of entry i), 4-deep ring.  Any k <= 32.
+// DB = false: TWO workgroups per CU (four waves per SIMD, <= 128 VGPRs: one fragment set, smaller entries, 3-deep ring, candidate
+//             columns of k + 16 slots so that both fit the LDS): a tile's epilogue costs a wave ~15 cycles per instruction
+//             whatever it is (two thirds of the r02 collect pass), and only more resident waves hide that.  k <= 12.
+template <int KS, int MODE, int KM, bool DB>
+__global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    constexpr int IT = EntryTiles<KS>::value;
+    constexpr int IT = DB ? EntryTiles<KS>::value : (KS >= 8 ? 1 : KS == 4 ? 2 : 4);
+    constexpr int NB = DB ? NBUF : 3;
     constexpr int TILE_BYTES = KS * 1024;
     constexpr int ENTRY_BYTES = IT * TILE_BYTES;           // one ring entry = IT consecutive item tiles
     constexpr int PIECES = IT * KS;                        // 1 KiB LDS-DMA pieces per entry
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);       // low half of the flat address = LDS offset
     // entry e of this slice = tiles t0 + IT e .. + IT - 1 = PIECES consecutive 1 KiB pieces of the plane table
     auto prefetch = [&](int e) __attribute__((always_inline)) {
-        const int buf = e & (NBUF - 1);
+        const int buf = DB ? (e & (NBUF - 1)) : e % NB;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int p = wv + WAVES * i;
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
 
     // ---- per-lane state ----
     const int CAP = a.cap;
-    uint32_t *cand = reinterpret_cast<uint32_t *>(smem + NBUF * ENTRY_BYTES) + wv * (CAP * 64);  // [slot][lane]
+    uint32_t *cand = reinterpret_cast<uint32_t *>(smem + NB * ENTRY_BYTES) + wv * (CAP * 64);  // [slot][lane]
     int cnt = 0;
     // Collect pass: the accumulators start at BIAS + r / 16 instead of 0 (r = register = row of the lane's 16), so an element
     // is v = BIAS + dot + r / 16: exact in f32 (|dot| <= 512, 4 fraction bits, v in [2560, 3585) = one binade), ordered by
@@ -316,9 +322,9 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
     // first use of a query fragment INSIDE the loop, i.e. drain the ring on every tile)
     __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
 #pragma unroll
-    for (int j = 0; j < NBUF - 1; ++j)
+    for (int j = 0; j < NB - 1; ++j)
         if (j < nt) prefetch(j);
-    v4i avA[IT][KS], avB[IT][KS];
+    v4i avA[IT][KS], avB[DB ? IT : 1][DB ? KS : 1];
     v16f acc[IT];
 #pragma unroll
     for (int u = 0; u < IT; ++u)
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
         for (int r = 0; r < 16; ++r) acc[u][r] = NO_DOT;
 
     auto read_entry = [&](int e, v4i (&av)[IT][KS]) __attribute__((always_inline)) {
-        const unsigned char *tb = smem + (e & (NBUF - 1)) * ENTRY_BYTES + lane * 16;
+        const unsigned char *tb = smem + (DB ? (e & (NBUF - 1)) : e % NB) * ENTRY_BYTES + lane * 16;
 #pragma unroll
         for (int u = 0; u < IT; ++u)
 #pragma unroll
@@ -369,14 +375,45 @@ __global__ __launch_bounds__(512, 2) void hamming_mfma_kernel(HArgs a) {
             if (PS_HM_DEBUG & 128) __builtin_amdgcn_s_setprio(0);
         }
     };
-    if (nt > 0) {
-        wait_entry(0);
-        if (!(PS_HM_DEBUG & 4)) __builtin_amdgcn_s_barrier();
-        read_entry(0, avA);
-    }
-    for (int i = 0; i < nt; i += 2) {
-        step(i, avA, avB);
-        if (i + 1 < nt) step(i + 1, avB, avA);
+    if constexpr (DB) {
+        if (nt > 0) {
+            wait_entry(0);
+            if (!(PS_HM_DEBUG & 4)) __builtin_amdgcn_s_barrier();
+            read_entry(0, avA);
+        }
+        for (int i = 0; i < nt; i += 2) {
+            step(i, avA, avB);
+            if (i + 1 < nt) step(i + 1, avB, avA);
+        }
+    } else {
+        // one fragment set: the reads of entry i are waited for in front of its MFMAs; the other three waves of the SIMD (two of
+        // them of the CU's second workgroup, which shares no barrier with this one) fill the gap
+        for (int i = 0; i < nt; ++i) {
+            // entry i: own pieces landed (entry i + 1 may be in flight); after the barrier everybody's have, and everybody is
+            // done with the MFMAs (= the fragment reads) of entry i - 1, whose buffer the next LDS-DMA overwrites
+            if (nt - 1 - i >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(PS_HM_DEBUG & 4)) __builtin_amdgcn_s_barrier();
+            if (i + NB - 1 < nt) prefetch(i + NB - 1);
+            read_entry(i, avA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (late && i > 0 && !(PS_HM_DEBUG & 1)) {
+#pragma unroll
+                for (int u = 0; u < IT; ++u) epilogue(acc[u], (i - 1) * IT + u);
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int u = 0; u < IT; ++u) {
+                    const v16f c = s == 0 ? cinit : acc[u];
+                    if (PS_HM_DEBUG & 8) acc[u][s & 15] += (float)(avA[u][s][0] ^ bq[s][1]);
+                    else acc[u] = sign_mfma(avA[u][s], bq[s], c);
+                }
+            if (!late && !(PS_HM_DEBUG & 1)) {
+#pragma unroll
+                for (int u = 0; u < IT; ++u) epilogue(acc[u], i * IT + u);
+            }
+        }
     }
     if (late && nt > 0 && !(PS_HM_DEBUG & 1)) {
 #pragma unroll
@@ -532,6 +569,7 @@ int key_shift_bits(int nbits) {
 struct Plan {
     bool ok;
     int KS, IT, nqb, slices, bslices, shift, km, cap;
+    bool db;                // collect pass: one workgroup per CU with two fragment sets (any k) or two per CU (k <= 12)
     int64_t tiles, tiles_per_slice, sample_tiles, btiles_per_slice;
     size_t off_thr, off_bl, off_i, off_d, total;
 };
@@ -552,13 +590,14 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     if (nq < 64 || N < 4096) return p;                    // small problems: the popcount kernel has no tile padding
     const int IT = p.KS >= 4 ? 2 : 4;                      // EntryTiles<KS>
     p.IT = IT;
-    p.cap = k <= 16 ? 32 : 48;                             // a lane's column: k kept + one tile's 16 rows
+    p.db = k > 12 || p.KS <= 2 || env_int("PS_HAMMING_MFMA_DB", 0) != 0;   // (KS <= 2: four tiles per entry do not fit 128 VGPRs)
+    p.cap = p.db ? (k <= 16 ? 32 : 48) : 28;               // a lane's column: k kept + one tile's 16 rows
     p.shift = key_shift_bits(cs * 8);
     p.tiles = (N + 31) >> 5;
     const int64_t nqt = (nq + 31) >> 5;
     p.nqb = (int)((nqt + WAVES - 1) / WAVES);
-    const int slots = env_int("PS_HAMMING_MFMA_SLOTS", 256);      // one 8-wave workgroup per CU
-    int64_t s = slots / p.nqb;
+    const int slots = env_int("PS_HAMMING_MFMA_SLOTS", 256);      // one 8-wave workgroup per CU (bound pass; collect pass with db)
+    int64_t s = (p.db ? slots : 2 * slots) / p.nqb;
     if (s < 1) s = 1;
     if (s > 64) s = 64;                                    // merge fan-in: 16 lanes per query up to 16 lists, a wave beyond
     while (s > 1 && p.tiles / s < 32) --s;                 // a slice is at least 32 tiles (1024 items)
@@ -574,7 +613,7 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     if (st <= 0) st = p.tiles / 5;
     if (st < 64) st = 64;
     if (st > p.tiles) st = p.tiles;
-    int64_t bs = slots / p.nqb;
+    int64_t bs = (p.db ? slots : 2 * slots) / p.nqb;
     if (bs < 1) bs = 1;
     if (bs > 16) bs = 16;                                  // <= 2 bs lists of KM <= 32 values per query (bound_select: 1024)
     while (bs > 1 && st / bs < 16) --bs;
@@ -605,16 +644,19 @@ bool allow_lds(K kernel, size_t bytes) {
 template <int KS>
 int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t *bl, int64_t nq) {
     constexpr int IT = EntryTiles<KS>::value;
+    constexpr int IT1 = KS >= 8 ? 1 : KS == 4 ? 2 : 4;      // entry of the two-workgroups-per-CU collect kernel
     const size_t tiles_lds = (size_t)NBUF * IT * KS * 1024;
-    const size_t lds = tiles_lds + (size_t)WAVES * p.cap * 64 * sizeof(uint32_t);
+    const size_t lds = p.db ? tiles_lds + (size_t)WAVES * p.cap * 64 * sizeof(uint32_t)
+                            : (size_t)3 * IT1 * KS * 1024 + (size_t)WAVES * p.cap * 64 * sizeof(uint32_t);
     // once per (kernel, device): one process may drive several GPUs
     static bool lds_done[64] = {};
     int devid = 0;
     if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PS_ELAUNCH;
     bool lds_ok = lds_done[devid];
     if (!lds_ok) {
-        lds_ok = allow_lds(hamming_mfma_kernel<KS, 0, 4>, 160 * 1024) && allow_lds(hamming_mfma_kernel<KS, 0, 16>, 160 * 1024) &&
-                 allow_lds(hamming_mfma_kernel<KS, 0, 32>, 160 * 1024) && allow_lds(hamming_mfma_kernel<KS, 1, 4>, 160 * 1024);
+        lds_ok = allow_lds(hamming_mfma_kernel<KS, 0, 4, true>, 160 * 1024) && allow_lds(hamming_mfma_kernel<KS, 0, 16, true>, 160 * 1024) &&
+                 allow_lds(hamming_mfma_kernel<KS, 0, 32, true>, 160 * 1024) && allow_lds(hamming_mfma_kernel<KS, 1, 4, true>, 160 * 1024) &&
+                 allow_lds(hamming_mfma_kernel<KS, 1, 4, false>, 80 * 1024) && allow_lds(hamming_mfma_kernel<KS, 0, 4, false>, 80 * 1024);
         lds_done[devid] = lds_ok;
     }
     if (!lds_ok) return PS_ELAUNCH;
@@ -624,9 +666,10 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
     HArgs b = a;
     b.tile_begin = 0; b.tile_end = p.sample_tiles; b.tiles_per_slice = p.btiles_per_slice; b.slices = p.bslices; b.bl = bl;
     const unsigned gb = (unsigned)(p.nqb * p.bslices);
-    if (p.km == 4) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 4>), dim3(gb), dim3(512), tiles_lds, st, b);
-    else if (p.km == 16) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 16>), dim3(gb), dim3(512), tiles_lds, st, b);
-    else hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 32>), dim3(gb), dim3(512), tiles_lds, st, b);
+    if (p.km == 4 && !p.db) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 4, false>), dim3(gb), dim3(512), (size_t)3 * IT1 * KS * 1024, st, b);
+    else if (p.km == 4) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 4, true>), dim3(gb), dim3(512), tiles_lds, st, b);
+    else if (p.km == 16) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 16, true>), dim3(gb), dim3(512), tiles_lds, st, b);
+    else hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 32, true>), dim3(gb), dim3(512), tiles_lds, st, b);
     PS_CHECK_LAUNCH();
     int64_t gs = ps_cdiv(nq, 4);
     if (gs > 4096) gs = 4096;
@@ -636,7 +679,8 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
     a.tile_begin = 0; a.tile_end = p.tiles; a.tiles_per_slice = p.tiles_per_slice; a.slices = p.slices; a.thr0 = thr0;
     a.list_base = 0;
     const unsigned gc = (unsigned)(p.nqb * p.slices);
-    hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 4>), dim3(gc), dim3(512), lds, st, a);
+    if (p.db) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 4, true>), dim3(gc), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 4, false>), dim3(gc), dim3(512), lds, st, a);
     PS_CHECK_LAUNCH();
     return PS_OK;
 }
