@@ -242,6 +242,8 @@ def main():
         timer = nv.KernelTimer()
         recs = []
         pipe.overlap_sampling = False       # per-kernel durations are measured with the kernels running alone
+        overlap_proj = pipe.overlap_input_proj
+        pipe.overlap_input_proj = False
         sync_all()
         nv.set_timer(timer)
         t1 = time.perf_counter()
@@ -251,6 +253,7 @@ def main():
         elapsed_instr = time.perf_counter() - t1
         nv.set_timer(None)
         pipe.overlap_sampling = False
+        pipe.overlap_input_proj = overlap_proj
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -187,6 +187,8 @@ class ShardedPinSage:
         self.lo, self.hi, self.chunk = shard_range(self.M, self.rank, self.world)
         self._nodes = {}                   # device -> arange(lo, hi): made once, not per step
         self.overlap_sampling = False      # measured: no gain on MI355X (2.69 vs 2.65 ms per pass)
+        self.overlap_input_proj = False    # numpy-stream mode: input projection beside the MT19937 generator -- measured r03: no
+                                           # gain (1.224 vs 1.213 ms per embed pass: the 46 us GEMM hides, the stream hand-over costs it back)
         self.fuse_self = True
         self._streams = {}
         self._fused = {}                   # layer -> (W1, b1) composed from the snapshot `params`
@@ -243,6 +245,20 @@ class ShardedPinSage:
         # order) while the main stream runs the projections; each pooling waits for its own batch only.
         side = self._side_stream(dev) if (self.overlap_sampling and x_local.is_cuda) else None
         batches, ready = [], []
+        # numpy-stream mode: the MT19937 generator that opens the sampling (a chain of low-occupancy kernels, 0.2 ms) has
+        # nothing to do with the input projection, the only dense work that does not wait for the samples: the projection
+        # runs beside it on a second stream (r02 measured generator || GEMMs = 0.91 ms against 1.03 ms back to back, and
+        # the SAMPLER beside GEMMs = no gain, which is why only this pair is overlapped)
+        early_h = None
+        if (self.overlap_input_proj and fused and x_local.is_cuda and getattr(self.sampler, "rng", None) == "numpy"
+                and not (x_full is not None and self.world > 1)):
+            main = torch.cuda.current_stream(dev)
+            aux = self._side_stream(dev)
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                early_h = ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
+                early_ready = aux.record_event()
+            early_h.record_stream(main)
         if fused:
             batches = list(ops.sample_layers(self.sampler, self.lo, self.hi, T, self.num_layers, shard))
         elif side is not None:
@@ -257,12 +273,14 @@ class ShardedPinSage:
                     ready.append(side.record_event())
         else:
             batches.append(self._sample(nodes, T, shard))
+        if early_h is not None:
+            torch.cuda.current_stream(dev).wait_event(early_ready)             # behind the sampling kernels enqueued above
         if x_full is not None and self.world > 1:
             h_all = ops.linear(x_full, P["input_proj.weight"], P["input_proj.bias"], relu=True)
             h = h_all[self.lo:self.hi]
             pending = _Gather(h_all)
         else:
-            h = ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
+            h = early_h if early_h is not None else ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
             pending = self.comm.gather_rows_async(h, self.chunk, "h")
         for i in range(self.num_layers):
             if side is None and not fused and i + 1 < self.num_layers:

@@ -17,8 +17,13 @@ _RATING_VALUES = [0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0, 4.5, 5.0]
 _RATING_P = [.016, .031, .016, .066, .050, .196, .127, .266, .088, .144]
 
 
-def bipartite_ratings(num_users, num_items, num_ratings, seed=20240601, device="cpu", zipf_c=42.0, zipf_s=1.0):
-    """-> (edge_index int64[2, 2R], edge_weights fp32[2R]) on `device`."""
+def bipartite_ratings(num_users, num_items, num_ratings, seed=20240601, device="cpu", zipf_c=42.0, zipf_s=1.0, unique=False):
+    """-> (edge_index int64[2, 2R], edge_weights fp32[2R]) on `device`.
+    unique=True: every (user, item) pair occurs at most once, like real rating logs; pairs drawn twice are
+    redrawn until R distinct ones exist (the benchmark graphs keep the with-replacement draw they have been measured on).
+    The draw uses torch's generator of `device`: a graph is reproducible per device type, not across CPU and GPU."""
+    if unique:
+        return _unique_ratings(num_users, num_items, num_ratings, seed, device, zipf_c, zipf_s)
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(int(seed))
@@ -49,3 +54,59 @@ def bipartite_ratings(num_users, num_items, num_ratings, seed=20240601, device="
     edge_index = torch.stack([torch.cat([u, items]), torch.cat([items, u])]).to(torch.int64)
     edge_weights = torch.cat([ratings, ratings])
     return edge_index, edge_weights
+
+
+def _unique_ratings(U, M, R, seed, device, zipf_c, zipf_s):
+    U, M, R = int(U), int(M), int(R)
+    if R > U * M:
+        raise ValueError("more ratings than (user, item) pairs")
+    have = None
+    extra = 0
+    for attempt in range(64):
+        want = R + extra
+        ei, ew = bipartite_ratings(U, M, max(want, M), seed=int(seed) + attempt, device=device, zipf_c=zipf_c, zipf_s=zipf_s)
+        n = ei.size(1) // 2
+        key = (ei[0, :n] - M) * M + ei[1, :n]                  # user * M + item, rows in the generator's shuffled order
+        if have is not None:
+            key = torch.cat([have[0], key])
+            rat = torch.cat([have[1], ew[:n]])
+        else:
+            rat = ew[:n]
+        # first occurrence of every pair, original order kept
+        uniq, inv = torch.unique(key, return_inverse=True)
+        first = torch.full((uniq.numel(),), key.numel(), dtype=torch.int64, device=key.device)
+        first.scatter_reduce_(0, inv, torch.arange(key.numel(), device=key.device), reduce="amin")
+        keep = torch.sort(first).values
+        key, rat = key[keep], rat[keep]
+        if key.numel() >= R:
+            key, rat = key[:R], rat[:R]
+            u, it = key // M + M, key % M
+            u[-1] = M + U - 1 if not bool((key // M == U - 1).any()) else u[-1]     # V = M + U exactly
+            return torch.stack([torch.cat([u, it]), torch.cat([it, u])]).to(torch.int64), torch.cat([rat, rat])
+        have = (key, rat)
+        extra = max(R - key.numel(), 1024) * 2
+    raise RuntimeError("could not draw enough distinct pairs")
+
+
+def write_movielens_csv(out_dir, num_users, num_items, num_ratings, seed=20240601, device="cpu"):
+    """Writes the graph as the MovieLens files the reference reads (data/dataset.py:46-70): ratings.csv
+    (userId,movieId,rating,timestamp; ids 1-based, rows in the generator's order, distinct pairs) and movies.csv
+    (movieId,title,genres).  Returns the two paths.  `ingest.build_graph_from_csv(ratings.csv)` rebuilds the graph with the
+    reference's first-appearance numbering."""
+    import os
+
+    import numpy as np
+    import pandas as pd
+    ei, ew = bipartite_ratings(num_users, num_items, num_ratings, seed=seed, device=device, unique=True)
+    R = ei.size(1) // 2
+    users = (ei[0, :R] - int(num_items) + 1).cpu().numpy()
+    items = (ei[1, :R] + 1).cpu().numpy()
+    os.makedirs(out_dir, exist_ok=True)
+    rp, mp = os.path.join(out_dir, "ratings.csv"), os.path.join(out_dir, "movies.csv")
+    pd.DataFrame({"userId": users, "movieId": items, "rating": ew[:R].cpu().numpy().astype(np.float64),
+                  "timestamp": 1_500_000_000 + np.arange(R, dtype=np.int64)}).to_csv(rp, index=False)
+    genres = ["Action", "Comedy", "Drama", "Sci-Fi", "Thriller", "Romance"]
+    mid = np.arange(1, int(num_items) + 1)
+    pd.DataFrame({"movieId": mid, "title": [f"Synthetic Movie {i} ({1990 + i % 30})" for i in mid],
+                  "genres": [genres[i % 6] + "|" + genres[(i // 6) % 6] for i in mid]}).to_csv(mp, index=False)
+    return rp, mp

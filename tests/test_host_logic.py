@@ -273,3 +273,27 @@ def test_training_recipe_reproduces_reference_losses(golden2):
     assert [f"Epoch {i + 1}/3 - Loss: {m:.4f}" for i, m in enumerate(epoch_means)] == list(g["g10_epoch_loss_strings"])
     for k, v in model.state_dict().items():
         np.testing.assert_allclose(v.numpy(), g["g10_final_" + k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_synthetic_generator_unique_pairs_and_movielens_csv(tmp_path):
+    """the synthetic generator can emit distinct (user, item) pairs and the MovieLens CSV schema the reference
+    reads (data/dataset.py:46-70); the CSV goes back through the ingest path with the reference's first-appearance numbering."""
+    import pandas as pd
+    from pinsage_hip import ingest, synth
+    U, M, R = 300, 200, 9000
+    ei, ew = synth.bipartite_ratings(U, M, R, seed=5, unique=True)
+    assert ei.shape == (2, 2 * R) and ew.shape == (2 * R,)
+    u, it = ei[0, :R] - M, ei[1, :R]
+    assert int(u.min()) >= 0 and int(u.max()) == U - 1 and int(it.min()) >= 0 and int(it.max()) < M
+    assert torch.unique(u * M + it).numel() == R                                      # no pair twice
+    assert torch.equal(ei[0, R:], ei[1, :R]) and torch.equal(ei[1, R:], ei[0, :R]) and torch.equal(ew[:R], ew[R:])
+    assert set(ew.tolist()) <= {0.5 * k for k in range(1, 11)}
+    assert torch.equal(synth.bipartite_ratings(U, M, R, seed=5, unique=True)[0], ei)   # deterministic
+    rp, mp = synth.write_movielens_csv(str(tmp_path), U, M, R, seed=5)
+    df, mv = pd.read_csv(rp), pd.read_csv(mp)
+    assert list(df.columns) == ["userId", "movieId", "rating", "timestamp"] and list(mv.columns) == ["movieId", "title", "genres"]
+    assert len(df) == R and len(mv) == M and not df.duplicated(["userId", "movieId"]).any()
+    ei2, ew2, movies, users = ingest.build_graph_from_csv(rp)
+    assert ei2.shape == (2, 2 * R) and len(movies) <= M and len(users) <= U
+    # first-appearance numbering: the first row's movie and user get index 0
+    assert int(ei2[1, 0]) == 0 and int(ei2[0, 0]) == len(movies) and movies[0] == df["movieId"][0] and users[0] == df["userId"][0]
