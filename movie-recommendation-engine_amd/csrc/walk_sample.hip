@@ -39,6 +39,7 @@ struct WalkArgs {
     int stage_blocks;   // start rows of at most this many 128-byte blocks are searched in LDS
     int region_words;   // LDS words shared by the staged row (walk phase) and the hash table (count phase)
     const unsigned char *buckets;   // 64-byte bucket records (ps_bucket_build) or NULL
+    int bitmap_words;               // LDS words of the count-class bitmap: W * L / 32 + 1, padded
     int rounds;                     // independent samples per start node (one per GCN layer), all in one wave
     int64_t round_stride;           // PS_RNG_STREAM: uniforms of round r start at r * round_stride + uoff[i]
 };
@@ -317,7 +318,7 @@ extern "C" int ps_debug_ws_trace(unsigned long long *host) {
 #define PS_WS_STAMP(slot) do {} while (0)
 #endif
 constexpr int WAVES_PER_BLOCK = 1;   // one start node per workgroup: the dispatcher load-balances uneven nodes
-constexpr int BITMAP_WORDS = 40;   // counts <= 1024 -> 33 words, padded
+constexpr int BITMAP_WORDS = 40;   // counts <= 1024 -> 33 words, padded (larger W * L: WalkArgs::bitmap_words)
 
 template <int NP>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkArgs a) {
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
     const int HS = 1 << a.hs_log2;
     const int P = a.W * a.L;
     const int R = a.rounds;
-    const int per_wave = R * NP * 64 + a.region_words + BITMAP_WORDS;
+    const int per_wave = R * NP * 64 + a.region_words + a.bitmap_words;
     int32_t *posb_all = smem + wv * per_wave;               // visited ids of every round, [round][walk * L + step]
     int32_t *hkey = posb_all + R * NP * 64;
     int32_t *hcnt = hkey + HS;
@@ -620,35 +621,55 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
     if (packed && !nodeinfo) return PS_EINVAL;
     if (buckets && (!nodeinfo || reinterpret_cast<size_t>(buckets) % 64 != 0)) return PS_EINVAL;
     const int64_t P = (int64_t)W * L;
-    if (P > 1024) return PS_EUNSUPPORTED;
+    if (P > 4096) return PS_EUNSUPPORTED;                  // 64 positions per lane: registers (vid / slot / cr) and 160 KiB of LDS end here
     int np = 1;
     while (np * 64 < P) np <<= 1;
     int hs_log2 = 6;
     while ((1 << hs_log2) * 4 < 5 * P) ++hs_log2;      // table >= 1.25 P slots (load factor <= 0.8)
     WalkArgs a{rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff,
-               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0, reinterpret_cast<const unsigned char *>(buckets),
+               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0, reinterpret_cast<const unsigned char *>(buckets), 0,
                rounds, round_stride};
     // LDS budget: the kernel holds 24 waves per CU by registers; 160 KB / 24 leaves ~6.6 KB per wave, and whatever
     // the position buffers and the hash table do not need of that lets longer start rows be staged.
     const int hash_words = 3 * (1 << hs_log2);
-    int region_words = (6656 / 4) - rounds * np * 64 - BITMAP_WORDS;
+    const int bitmap_words = P <= 1024 ? BITMAP_WORDS : (int)(((P >> 5) + 1 + 7) & ~7);
+    a.bitmap_words = bitmap_words;
+    int region_words = (6656 / 4) - rounds * np * 64 - bitmap_words;
     if (region_words < hash_words) region_words = hash_words;
     region_words &= ~31;                                    // whole 128-byte blocks
     a.region_words = region_words;
     a.stage_blocks = packed ? region_words / 32 : 0;
-    const size_t lds = (size_t)WAVES_PER_BLOCK * (rounds * np * 64 + region_words + BITMAP_WORDS) * sizeof(int32_t);
-    if (lds > 64 * 1024) return PS_EUNSUPPORTED;
+    const size_t lds = (size_t)WAVES_PER_BLOCK * (rounds * np * 64 + region_words + bitmap_words) * sizeof(int32_t);
+    if (lds > 160 * 1024) return PS_EUNSUPPORTED;            // (e.g. eight fused layers of 4096 positions each)
     int64_t grid = ps_cdiv(B, WAVES_PER_BLOCK);
     if (grid > (int64_t)1 << 30) grid = (int64_t)1 << 30;
     hipStream_t st = ps_stream(stream);
+    // dynamic LDS beyond 64 KiB (W * L > 1024 only) has to be allowed per kernel and device, once
+#define PS_WS_LAUNCH(NP_)                                                                                                      \
+    do {                                                                                                                       \
+        if (lds > 64 * 1024) {                                                                                                 \
+            static bool done[64] = {};                                                                                         \
+            int dv = 0;                                                                                                        \
+            if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= 64) return PS_ELAUNCH;                                      \
+            if (!done[dv]) {                                                                                                   \
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(walk_sample_kernel<NP_>),                               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PS_ELAUNCH; \
+                done[dv] = true;                                                                                               \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        hipLaunchKernelGGL(walk_sample_kernel<NP_>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a);             \
+    } while (0)
     switch (np) {
-        case 1: hipLaunchKernelGGL(walk_sample_kernel<1>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); break;
-        case 2: hipLaunchKernelGGL(walk_sample_kernel<2>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); break;
-        case 4: hipLaunchKernelGGL(walk_sample_kernel<4>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); break;
-        case 8: hipLaunchKernelGGL(walk_sample_kernel<8>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); break;
-        case 16: hipLaunchKernelGGL(walk_sample_kernel<16>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); break;
+        case 1: PS_WS_LAUNCH(1); break;
+        case 2: PS_WS_LAUNCH(2); break;
+        case 4: PS_WS_LAUNCH(4); break;
+        case 8: PS_WS_LAUNCH(8); break;
+        case 16: PS_WS_LAUNCH(16); break;
+        case 32: PS_WS_LAUNCH(32); break;
+        case 64: PS_WS_LAUNCH(64); break;
         default: return PS_EUNSUPPORTED;
     }
+#undef PS_WS_LAUNCH
     PS_CHECK_LAUNCH();
     return PS_OK;
 }

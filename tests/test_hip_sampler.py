@@ -217,9 +217,9 @@ def test_error_paths_raise_loudly():
     from utils.random_walk import RandomWalkSampler
     from utils.nearest_neighbors import LSHIndex
     ei, ew = bipartite_graph(50, 40, 600, 2, "half")
-    s = RandomWalkSampler(torch.from_numpy(ei), torch.from_numpy(ew), walk_length=11, num_walks=100, rng="philox")
+    s = RandomWalkSampler(torch.from_numpy(ei), torch.from_numpy(ew), walk_length=41, num_walks=100, rng="philox")
     with pytest.raises(native.NativeError, match="unsupported"):
-        s.sample_batch([0, 1], 5)                                   # W * L = 1100 > 1024 positions per wave
+        s.sample_batch([0, 1], 5)                                   # W * L = 4100 > 4096 positions per wave
     with pytest.raises(ValueError):
         sampling.walk_sample(s.graph, [0], 5, rng="xorshift")
     with pytest.raises(ValueError):
@@ -412,3 +412,31 @@ def test_ppr_helpers_match_the_reference(golden2):
     top = s.precompute_top_neighbors(nodes, num_neighbors=4)
     assert np.array_equal(np.array([top[n][0] for n in nodes]), g["g11_top_ids"])
     np.testing.assert_allclose(np.array([top[n][1] for n in nodes]), g["g11_top_w"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("W,L,T,rng", [(300, 4, 25, "philox"), (1000, 3, 50, "numpy"), (2048, 2, 10, "philox"), (137, 9, 7, "numpy")])
+def test_more_than_1024_positions_per_start_node(W, L, T, rng):
+    """num_walks * walk_length beyond 1024 (the reference takes any: utils/random_walk.py:98) up to 4096 positions per start
+    node: 32 / 64 positions per lane, a larger count bitmap and hash table in (up to 160 KiB of) LDS.  ids / counts vs the C
+    oracle, in both RNG modes, one and two fused layers."""
+    from oracle import c_oracle as co
+    from pinsage_hip import sampling
+    from pinsage_hip.graph import DeviceGraph
+    ei, ew = bipartite_graph(120, 90, 5000, 31, "half")
+    g = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew))
+    cg = co.Graph(ei, ew)
+    nodes = np.arange(0, 210, 3)
+    if rng == "philox":
+        got = sampling.walk_sample(g, nodes, T, W, L, rng="philox", seed=9, call=2)
+        two = sampling.walk_sample_layers(g, nodes, T, 2, W, L, rng="philox", seed=9, call=2)
+        ids, counts, nv, _, _, _ = co.walk_sample(cg, nodes, T, L, W, philox=(9, 2), threads=4)
+        ids1, counts1, nv1, _, _, _ = co.walk_sample(cg, nodes, T, L, W, philox=(9, 3), threads=4)
+        assert np.array_equal(two[1].ids.cpu().numpy(), ids1) and np.array_equal(two[1].counts.cpu().numpy(), counts1)
+        assert torch.equal(two[0].ids, got.ids) and torch.equal(two[0].counts, got.counts)
+    else:
+        uoff, n = cg.uniform_offsets(nodes, W, L)
+        u = np.random.RandomState(3).random_sample(n)
+        got = sampling.walk_sample(g, nodes, T, W, L, rng="numpy", uniforms=torch.from_numpy(u).cuda())
+        ids, counts, nv, _, _, _ = co.walk_sample(cg, nodes, T, L, W, uniforms=u)
+    assert np.array_equal(got.ids.cpu().numpy(), ids) and np.array_equal(got.counts.cpu().numpy(), counts)
+    assert np.array_equal(got.nvalid.cpu().numpy(), nv)
