@@ -6,7 +6,7 @@
 #   default/pmc_mfma.txt                : MFMA / VALU busy counters
 # usage: tools/profile_round.sh r02   (run through gpurun; rocprofv3 gets the program itself after --)
 set -u
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
