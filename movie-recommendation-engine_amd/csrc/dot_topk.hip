@@ -59,24 +59,36 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
         uint64_t worst = EMPTY_KEY;
         int filled = 0;
         if (!dry)
-            for (int64_t j = lane; j < N; j += 64) {
-                float v = s[j];
-                if (MODE == 1) {
-                    if (assign) {
-                        const int32_t a = assign[j];
-                        if (!((probe[row * words + (a >> 5)] >> (a & 31)) & 1u)) continue;   // list not probed
-                    }
-                    v = (qnr + xn[j]) - 2.f * v;
+            for (int64_t j0 = lane; j0 < N; j0 += 512) {           // eight elements per lane requested together: a lane-strided loop
+                float sv[8], xv[8];                                 // with one load in flight ran at 1.7 TB/s of the similarity slab
+                int32_t av[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t j = j0 + 64 * u;
+                    const bool ok = j < N;
+                    sv[u] = ok ? s[j] : 0.f;
+                    xv[u] = (MODE == 1 && ok) ? xn[j] : 0.f;
+                    av[u] = (MODE == 1 && assign && ok) ? assign[j] : 0;
                 }
-                if (j == self) v = -INFINITY;
-                const uint64_t key = ((uint64_t)(MODE == 1 ? ~desc_key(v) : desc_key(v)) << 32) | (uint32_t)j;
-                if (!first && key <= after) continue;
-                if (key < worst) {
-                    int p = filled < kk ? filled : kk - 1;
-                    while (p > 0 && col[(p - 1) * 64] > key) { col[p * 64] = col[(p - 1) * 64]; --p; }
-                    col[p * 64] = key;
-                    if (filled < kk) ++filled;
-                    if (filled == kk) worst = col[(kk - 1) * 64];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t j = j0 + 64 * u;
+                    if (j >= N) continue;
+                    float v = sv[u];
+                    if (MODE == 1) {
+                        if (assign && !((probe[row * words + (av[u] >> 5)] >> (av[u] & 31)) & 1u)) continue;   // list not probed
+                        v = (qnr + xv[u]) - 2.f * v;
+                    }
+                    if (j == self) v = -INFINITY;
+                    const uint64_t key = ((uint64_t)(MODE == 1 ? ~desc_key(v) : desc_key(v)) << 32) | (uint32_t)j;
+                    if (!first && key <= after) continue;
+                    if (key < worst) {
+                        int p = filled < kk ? filled : kk - 1;
+                        while (p > 0 && col[(p - 1) * 64] > key) { col[p * 64] = col[(p - 1) * 64]; --p; }
+                        col[p * 64] = key;
+                        if (filled < kk) ++filled;
+                        if (filled == kk) worst = col[(kk - 1) * 64];
+                    }
                 }
             }
         int head = 0;

@@ -50,7 +50,7 @@ def per_call(pred):
 
 
 out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps {steps} --warmup 1 --no-cpu-baseline ({label})",
-       "units": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB * 1024, as reported (no gfx950 wide-stream correction applied: narrow gathers are uncalibrated)",
+       "units": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB * 1024, as reported.  Calibration (profiles/r03_config5/pmc_calibration.txt): narrow gathers (8-byte / 64-byte random reads: the sampler) count exactly one 64-byte sector per request = real fabric traffic; wide coalesced streams count at 0.50 and random 1 KiB rows at 0.28 of their bytes (GEMM operands, pooling rows: multiply before comparing with a byte count)",
        "ps_walk_sample": per_launch(lambda k: k.startswith("walk_sample_kernel")),
        "ps_walk_sample_layers": per_launch(lambda k: k.startswith("walk_sample_kernel")),
        "ps_hamming_topk_mfma": per_launch(lambda k: k.startswith("hamming_mfma_kernel") or k.startswith("bound_select_kernel")
