@@ -32,6 +32,70 @@ __device__ __forceinline__ float key_value(uint32_t kk) {
     return __uint_as_float(b);
 }
 
+// Exact selection of the kk smallest 64-bit keys (value key << 32 | id: unique) a wave sees, with ONE threshold for the whole
+// wave: a key is admitted iff it is smaller than the kk-th smallest seen so far (and, in a later sweep, larger than the last key
+// already emitted).  Admitted keys go to a 256-slot queue in LDS (slots by ballot + prefix count, no atomics); when fewer than
+// 64 slots are free the queue is reduced to its kk smallest (kk rounds of a wave minimum over four keys per lane) and the
+// threshold tightened.  A row of N elements admits ~kk ln(N / kk) keys in all.  The first version kept a sorted list per LANE:
+// with 64 private thresholds some lane was inserting at nearly every element, and the wave sat in a divergent LDS insertion
+// loop for the whole row (1.06 ms per 4 546 x 59 047 slab).
+constexpr int SELQ = 256;
+__device__ __forceinline__ uint64_t wave_min_key(uint64_t v) {
+#define PS_STEP(ctrl, rows)                                                                                     \
+    {                                                                                                           \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)v, ctrl, rows, 0xf, false); \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(v >> 32), ctrl, rows, 0xf, false); \
+        const uint64_t o = ((uint64_t)hi << 32) | lo;                                                           \
+        v = o < v ? o : v;                                                                                      \
+    }
+    PS_STEP(0xB1, 0xf) PS_STEP(0x4E, 0xf) PS_STEP(0x141, 0xf) PS_STEP(0x140, 0xf) PS_STEP(0x142, 0xa) PS_STEP(0x143, 0xc)
+#undef PS_STEP
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+struct WaveSelect {
+    uint64_t *q;          // LDS, SELQ keys of this wave
+    int lane, kk, cnt;    // cnt: wave-uniform
+    uint64_t thr, after;  // wave-uniform: admit iff after < key < thr (after = 0 / first sweep: no lower bound)
+    bool first;
+    __device__ __forceinline__ void reset(int kk_) { kk = kk_; cnt = 0; thr = EMPTY_KEY; }
+    // queue -> its kk smallest in q[0 .. cnt), ascending; thr = the kk-th when there are kk
+    __device__ __forceinline__ void reduce() {
+        ps_wave_lds_sync();
+        uint64_t r[SELQ / 64];
+#pragma unroll
+        for (int u = 0; u < SELQ / 64; ++u) r[u] = (u * 64 + lane) < cnt ? q[u * 64 + lane] : EMPTY_KEY;
+        ps_wave_lds_sync();
+        int found = 0;
+        uint64_t last = EMPTY_KEY;
+        for (int t = 0; t < kk; ++t) {
+            uint64_t m = r[0];
+#pragma unroll
+            for (int u = 1; u < SELQ / 64; ++u) m = r[u] < m ? r[u] : m;
+            const uint64_t w = wave_min_key(m);
+            if (w == EMPTY_KEY) break;
+#pragma unroll
+            for (int u = 0; u < SELQ / 64; ++u) if (r[u] == w) r[u] = EMPTY_KEY;      // keys are unique
+            if (lane == 0) q[t] = w;
+            last = w;
+            ++found;
+        }
+        cnt = found;
+        if (found == kk) thr = last;
+        ps_wave_lds_sync();
+    }
+    __device__ __forceinline__ void offer(bool valid, uint64_t key) {         // converged call: every lane, valid or not
+        const bool adm = valid && key < thr && (first || key > after);
+        const uint64_t m = __ballot(adm);
+        if (m != 0ull) {
+            if (adm) q[cnt + __popcll(m & ((1ull << lane) - 1ull))] = key;
+            cnt += __popcll(m);
+            if (cnt > SELQ - 64) reduce();
+        }
+    }
+};
+
 // MODE 0: largest similarity first (exact inner-product search).  MODE 1: smallest L2 distance first,
 // dist = |q|^2 + |x|^2 - 2 q.x, optionally restricted to the items whose inverted list (assign) is probed.
 template <int MODE>
@@ -41,30 +105,27 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ assign,
                                                        const uint32_t *__restrict__ probe, int words,
                                                        float *__restrict__ vals, int64_t *__restrict__ ids) {
-    extern __shared__ uint64_t skeys[];   // [4 waves][kcap][64]
+    __shared__ uint64_t skeys[4 * SELQ];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint64_t *col = skeys + (size_t)wv * kcap * 64 + lane;
     const int64_t row = (int64_t)blockIdx.x * 4 + wv;
     if (row >= rows) return;
     const float *s = sims + row * N;
     const int64_t self = exclude_self ? qidx[row] : -1;
     const float qnr = (MODE == 1) ? qn[row] : 0.f;
-    // k > kcap (the per-lane columns of one sweep fill the LDS at 32 keys): further sweeps over the row, each admitting only
-    // keys AFTER the last one emitted -- keys are unique (id in the low word), so the sweeps partition the order exactly
-    uint64_t after = 0;
-    bool first = true, dry = false;
+    // k > kcap: further sweeps over the row, each admitting only keys AFTER the last one emitted -- keys are unique (id in the
+    // low word), so the sweeps partition the order exactly
+    WaveSelect sel{skeys + wv * SELQ, lane, 0, 0, EMPTY_KEY, 0, true};
+    bool dry = false;
     for (int base = 0; base < k; base += kcap) {
         const int kk = (k - base) < kcap ? (k - base) : kcap;
-        for (int p = 0; p < kk; ++p) col[p * 64] = EMPTY_KEY;
-        uint64_t worst = EMPTY_KEY;
-        int filled = 0;
+        sel.reset(kk);
         if (!dry)
-            for (int64_t j0 = lane; j0 < N; j0 += 512) {           // eight elements per lane requested together: a lane-strided loop
-                float sv[8], xv[8];                                 // with one load in flight ran at 1.7 TB/s of the similarity slab
+            for (int64_t j0 = 0; j0 < N; j0 += 512) {              // eight elements per lane requested together
+                float sv[8], xv[8];
                 int32_t av[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t j = j0 + 64 * u;
+                    const int64_t j = j0 + lane + 64 * u;
                     const bool ok = j < N;
                     sv[u] = ok ? s[j] : 0.f;
                     xv[u] = (MODE == 1 && ok) ? xn[j] : 0.f;
@@ -72,45 +133,28 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int64_t j = j0 + 64 * u;
-                    if (j >= N) continue;
+                    const int64_t j = j0 + lane + 64 * u;
+                    bool ok = j < N;
                     float v = sv[u];
                     if (MODE == 1) {
-                        if (assign && !((probe[row * words + (av[u] >> 5)] >> (av[u] & 31)) & 1u)) continue;   // list not probed
+                        if (assign && ok && !((probe[row * words + (av[u] >> 5)] >> (av[u] & 31)) & 1u)) ok = false;   // list not probed
                         v = (qnr + xv[u]) - 2.f * v;
                     }
                     if (j == self) v = -INFINITY;
-                    const uint64_t key = ((uint64_t)(MODE == 1 ? ~desc_key(v) : desc_key(v)) << 32) | (uint32_t)j;
-                    if (!first && key <= after) continue;
-                    if (key < worst) {
-                        int p = filled < kk ? filled : kk - 1;
-                        while (p > 0 && col[(p - 1) * 64] > key) { col[p * 64] = col[(p - 1) * 64]; --p; }
-                        col[p * 64] = key;
-                        if (filled < kk) ++filled;
-                        if (filled == kk) worst = col[(kk - 1) * 64];
-                    }
+                    sel.offer(ok, ((uint64_t)(MODE == 1 ? ~desc_key(v) : desc_key(v)) << 32) | (uint32_t)j);
                 }
             }
-        int head = 0;
-        for (int r = 0; r < kk; ++r) {
-            uint64_t mine = head < filled ? col[head * 64] : EMPTY_KEY;
-            uint64_t best = mine;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t lo = __shfl_xor((uint32_t)best, o, 64);
-                const uint32_t hi = __shfl_xor((uint32_t)(best >> 32), o, 64);
-                const uint64_t other = ((uint64_t)hi << 32) | lo;
-                best = other < best ? other : best;
-            }
-            if (mine == best && best != EMPTY_KEY) ++head;      // keys are unique (id in the low word)
-            if (best != EMPTY_KEY) after = best; else dry = true;   // nothing left: the remaining slots are padding
-            if (lane == 0) {
-                const uint32_t kb = (uint32_t)(best >> 32);
-                vals[row * k + base + r] = best != EMPTY_KEY ? key_value(MODE == 1 ? ~kb : kb) : (MODE == 1 ? 3.4028234663852886e38f : -INFINITY);
-                ids[row * k + base + r] = best != EMPTY_KEY ? (int64_t)(uint32_t)best : -1;
-            }
+        sel.reduce();
+        for (int r = lane; r < kk; r += 64) {
+            const uint64_t best = r < sel.cnt ? sel.q[r] : EMPTY_KEY;
+            const uint32_t kb = (uint32_t)(best >> 32);
+            vals[row * k + base + r] = best != EMPTY_KEY ? key_value(MODE == 1 ? ~kb : kb) : (MODE == 1 ? 3.4028234663852886e38f : -INFINITY);
+            ids[row * k + base + r] = best != EMPTY_KEY ? (int64_t)(uint32_t)best : -1;
         }
-        first = false;
+        if (sel.cnt < kk) dry = true;                                 // nothing left: the remaining slots are padding
+        else sel.after = sel.q[kk - 1];
+        sel.first = false;
+        ps_wave_lds_sync();
     }
 }
 
@@ -271,29 +315,16 @@ __global__ __launch_bounds__(256) void ivf_row_topk_kernel(const float *__restri
                                                            const int64_t *__restrict__ seg_off, const int64_t *__restrict__ item_ids,
                                                            int k, int kcap, const float *__restrict__ qn, const float *__restrict__ xn,
                                                            float *__restrict__ vals, int64_t *__restrict__ ids) {
-    extern __shared__ uint64_t skeys[];   // [4 waves][kcap][64]
+    __shared__ uint64_t skeys[4 * SELQ];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint64_t *col = skeys + (size_t)wv * kcap * 64 + lane;
     const int64_t row = (int64_t)blockIdx.x * 4 + wv;
     if (row >= rows) return;
     const float qnr = qn[row];
-    uint64_t after = 0;
-    bool first = true, dry = false;
+    WaveSelect sel{skeys + wv * SELQ, lane, 0, 0, EMPTY_KEY, 0, true};
+    bool dry = false;
     for (int base = 0; base < k; base += kcap) {
         const int kk = (k - base) < kcap ? (k - base) : kcap;
-        for (int p = 0; p < kk; ++p) col[p * 64] = EMPTY_KEY;
-        uint64_t worst = EMPTY_KEY;
-        int filled = 0;
-        auto offer = [&](uint64_t key) __attribute__((always_inline)) {
-            if (!first && key <= after) return;
-            if (key < worst) {
-                int p = filled < kk ? filled : kk - 1;
-                while (p > 0 && col[(p - 1) * 64] > key) { col[p * 64] = col[(p - 1) * 64]; --p; }
-                col[p * 64] = key;
-                if (filled < kk) ++filled;
-                if (filled == kk) worst = col[(kk - 1) * 64];
-            }
-        };
+        sel.reset(kk);
         for (int pb = 0; pb < nprobe && !dry; pb += 64) {                    // 64 segments per round (nprobe is 20 by default)
             const int np = (nprobe - pb) < 64 ? (nprobe - pb) : 64;
             // lane pi: segment pi of this round
@@ -311,7 +342,7 @@ __global__ __launch_bounds__(256) void ivf_row_topk_kernel(const float *__restri
             int64_t iv[2][4];
             int seg = 0, off = 0;                                            // next piece to load: elements off.. of segment seg
             auto skip_empty = [&]() __attribute__((always_inline)) { while (seg < np && off >= __builtin_amdgcn_readlane(n, seg)) { ++seg; off = 0; } };
-            auto load_piece = [&](int buf) __attribute__((always_inline)) {                                 // wave-uniform (seg, off); advances to the next piece
+            auto load_piece = [&](int buf) __attribute__((always_inline)) {  // wave-uniform (seg, off); advances to the next piece
                 const int ns = __builtin_amdgcn_readlane(n, seg);
                 const int64_t sos = ((int64_t)__builtin_amdgcn_readlane((int)(so >> 32), seg) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)so, seg);
                 const int64_t j0s = ((int64_t)__builtin_amdgcn_readlane((int)(j0 >> 32), seg) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)j0, seg);
@@ -328,9 +359,8 @@ __global__ __launch_bounds__(256) void ivf_row_topk_kernel(const float *__restri
             auto process = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (iv[buf][u] < 0) continue;
                     const float v = (qnr + xv[buf][u]) - 2.f * sv[buf][u];
-                    offer(((uint64_t)(~desc_key(v)) << 32) | (uint32_t)iv[buf][u]);
+                    sel.offer(iv[buf][u] >= 0, ((uint64_t)(~desc_key(v)) << 32) | (uint32_t)iv[buf][u]);
                 }
             };
             skip_empty();
@@ -350,25 +380,16 @@ __global__ __launch_bounds__(256) void ivf_row_topk_kernel(const float *__restri
                 }
             }
         }
-        int head = 0;
-        for (int r = 0; r < kk; ++r) {
-            uint64_t mine = head < filled ? col[head * 64] : EMPTY_KEY;
-            uint64_t best = mine;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t lo = __shfl_xor((uint32_t)best, o, 64);
-                const uint32_t hi = __shfl_xor((uint32_t)(best >> 32), o, 64);
-                const uint64_t other = ((uint64_t)hi << 32) | lo;
-                best = other < best ? other : best;
-            }
-            if (mine == best && best != EMPTY_KEY) ++head;
-            if (best != EMPTY_KEY) after = best; else dry = true;
-            if (lane == 0) {
-                vals[row * k + base + r] = best != EMPTY_KEY ? key_value(~(uint32_t)(best >> 32)) : 3.4028234663852886e38f;
-                ids[row * k + base + r] = best != EMPTY_KEY ? (int64_t)(uint32_t)best : -1;
-            }
+        sel.reduce();
+        for (int r = lane; r < kk; r += 64) {
+            const uint64_t best = r < sel.cnt ? sel.q[r] : EMPTY_KEY;
+            vals[row * k + base + r] = best != EMPTY_KEY ? key_value(~(uint32_t)(best >> 32)) : 3.4028234663852886e38f;
+            ids[row * k + base + r] = best != EMPTY_KEY ? (int64_t)(uint32_t)best : -1;
         }
-        first = false;
+        if (sel.cnt < kk) dry = true;
+        else sel.after = sel.q[kk - 1];
+        sel.first = false;
+        ps_wave_lds_sync();
     }
 }
 
@@ -401,7 +422,6 @@ extern "C" int ps_dot_topk(const float *E, int64_t N, int D, const int64_t *qidx
     float *sims = reinterpret_cast<float *>(base);
     float *Q = reinterpret_cast<float *>(base + ((size_t)c * N * sizeof(float) + 255) / 256 * 256);
     const int kcap = k < TOPK_SWEEP ? k : TOPK_SWEEP;
-    const size_t lds = (size_t)4 * kcap * 64 * sizeof(uint64_t);
     for (int64_t q0 = 0; q0 < nq; q0 += c) {
         const int64_t rows = (nq - q0) < c ? (nq - q0) : c;
         int64_t g = ps_cdiv(rows * D, 256);
@@ -410,7 +430,7 @@ extern "C" int ps_dot_topk(const float *E, int64_t N, int D, const int64_t *qidx
         PS_CHECK_LAUNCH();
         const int rc = ps_linear(Q, rows, D, E, D, nullptr, (int)N, nullptr, 0, nullptr, 0, 0, sims, stream);
         if (rc != PS_OK) return rc;
-        hipLaunchKernelGGL(row_topk_kernel<0>, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), lds, st, sims, N, rows,
+        hipLaunchKernelGGL(row_topk_kernel<0>, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), 0, st, sims, N, rows,
                            qidx + q0, exclude_self, k, kcap, (const float *)nullptr, (const float *)nullptr,
                            (const int32_t *)nullptr, (const uint32_t *)nullptr, 0, vals + q0 * k, ids + q0 * k);
         PS_CHECK_LAUNCH();
@@ -448,12 +468,11 @@ extern "C" int ps_l2_topk(const float *X, int64_t N, int D, const float *Q, int6
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)g), dim3(256), 0, st, Q, nq, D, qn);
     PS_CHECK_LAUNCH();
     const int kcap = k < TOPK_SWEEP ? k : TOPK_SWEEP;
-    const size_t lds = (size_t)4 * kcap * 64 * sizeof(uint64_t);
     for (int64_t q0 = 0; q0 < nq; q0 += c) {
         const int64_t rows = (nq - q0) < c ? (nq - q0) : c;
         const int rc = ps_linear(Q + q0 * D, rows, D, X, D, nullptr, (int)N, nullptr, 0, nullptr, 0, 0, sims, stream);
         if (rc != PS_OK) return rc;
-        hipLaunchKernelGGL(row_topk_kernel<1>, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), lds, st, sims, N, rows,
+        hipLaunchKernelGGL(row_topk_kernel<1>, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), 0, st, sims, N, rows,
                            (const int64_t *)nullptr, 0, k, kcap, qn + q0, xn, assign, probe ? probe + q0 * words : nullptr, words,
                            dist + q0 * k, ids + q0 * k);
         PS_CHECK_LAUNCH();
@@ -521,7 +540,6 @@ extern "C" int ps_ivf_topk(const float *X, int64_t N, int D, const int64_t *list
     const size_t hist_lds = (size_t)nlist * sizeof(int32_t);
     if (hist_lds > 48 * 1024) return PS_EUNSUPPORTED;          // > 12 288 lists
     const int kcap = k < TOPK_SWEEP ? k : TOPK_SWEEP;
-    const size_t lds = (size_t)4 * kcap * 64 * sizeof(uint64_t);
     int64_t g;
     if (N > 0) {
         g = ps_cdiv(N, 4);
@@ -549,7 +567,7 @@ extern "C" int ps_ivf_topk(const float *X, int64_t N, int D, const int64_t *list
             const int rc = psi_linear_grouped(Qg, L.max_tiles * 64, D, X, D, slab, grp, (int)max_list, stream);
             if (rc != PS_OK) return rc;
         }
-        hipLaunchKernelGGL(ivf_row_topk_kernel, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), lds, st, slab, rows, pr, nprobe, nlist,
+        hipLaunchKernelGGL(ivf_row_topk_kernel, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), 0, st, slab, rows, pr, nprobe, nlist,
                            list_ptr, seg, item_ids, k, kcap, qn + q0, xn, dist + q0 * k, ids + q0 * k);
         PS_CHECK_LAUNCH();
     }
