@@ -132,6 +132,19 @@ __device__ __forceinline__ v16f sign_mfma(const v4i &a, const v4i &b, const v16f
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
+// The first K step of a tile in the collect pass: D = A x B + C with C = the row-encoding constants in registers of their own.
+// Written in asm because the compiler selects the form with the accumulator tied to C and copies the 16 constants into the
+// accumulator registers in front of every tile (eight v_mov_b64 per tile beside ~50 epilogue instructions).  The destination is
+// early-clobber (a 32 x 32 MFMA writes while it still reads); the operands come from ds_read_b128 / kernel-lifetime registers,
+// whose waits the compiler inserts for asm operands as for any use; the next MFMA reads this result as its C with exactly the
+// same registers, which the matrix pipe orders itself.
+__device__ __forceinline__ v16f sign_mfma_first(const v4i &a, const v4i &b, const v16f &c, int scale) {
+    v16f d;
+    asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+        : "=&v"(d) : "v"(a), "v"(b), "v"(c), "v"(scale));
+    return d;
+}
+
 // MODE 0 = bound pass, 1 = collect pass.  One wave = one tile of 32 queries (16 query-fragment registers per 32 bits
 // of code).  Per-tile work besides the MFMAs is ~11 vector instructions (this file is compiled with -fno-honor-nans:
 // every value is an integer held in f32, so the maxima are bare v_max3_f32 without sNaN-quieting copies): the maximum of a
@@ -405,9 +418,9 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
             for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int u = 0; u < IT; ++u) {
-                    const v16f c = s == 0 ? cinit : acc[u];
                     if (PS_HM_DEBUG & 8) acc[u][s & 15] += (float)(avA[u][s][0] ^ bq[s][1]);
-                    else acc[u] = sign_mfma(avA[u][s], bq[s], c);
+                    else if (s == 0 && MODE == 1 && !(PS_HM_DEBUG & 256)) acc[u] = sign_mfma_first(avA[u][s], bq[s], cinit, 0x7f7f7f7f);
+                    else acc[u] = sign_mfma(avA[u][s], bq[s], s == 0 ? cinit : acc[u]);
                 }
             if (!late && !(PS_HM_DEBUG & 1)) {
 #pragma unroll
@@ -541,6 +554,19 @@ __global__ __launch_bounds__(256) void bound_select_kernel(const int32_t *__rest
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    if (nvals <= 128) {                                      // the usual case (KM = 4 lists): two values per lane, two ballots per probe
+        for (int64_t q = wave; q < nq; q += nw) {
+            const int v0 = lane < nvals ? bl[q * nvals + lane] : 0x7fffffff;
+            const int v1 = lane + 64 < nvals ? bl[q * nvals + lane + 64] : 0x7fffffff;
+            int lo = 0, hi = nbits;                          // smallest d with #(v <= d) >= k, else nbits
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (__popcll(__ballot(v0 <= mid)) + __popcll(__ballot(v1 <= mid)) >= k) hi = mid; else lo = mid + 1;
+            }
+            if (lane == 0) thr0[q] = lo;
+        }
+        return;
+    }
     for (int64_t q = wave; q < nq; q += nw) {
         int v[16];                                           // nvals <= 1024 (make_plan)
 #pragma unroll
