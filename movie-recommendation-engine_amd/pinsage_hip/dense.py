@@ -117,7 +117,8 @@ def hamming_topk(qcodes, codes, k, id_offset=0, planes=None, use_mfma=True, out=
         if (tuple(dist.shape) != (nq, k) or tuple(ids.shape) != (nq, k) or dist.dtype != torch.int32
                 or ids.dtype != torch.int64 or not dist.is_contiguous() or not ids.is_contiguous()):
             raise ValueError("out must be contiguous (int32 [nq, k], int64 [nq, k])")
-    if k > HAMMING_MAX_K:
+    if k > HAMMING_MAX_K or cs > 128 or (cs & (cs - 1)) != 0 or cs % 4 != 0:
+        # beyond the scans' shapes (k > 64; codes longer than 1024 bits or not 32 * 2^j bits): exact L2 over the +-1 images
         d, i = _hamming_topk_large_k(qcodes, codes, k, id_offset)
         if out is None:
             return d, i

@@ -159,7 +159,7 @@ def test_aggregators_golden(golden):
         A.MeanAggregator()(f, [[99]])
 
 
-@pytest.mark.parametrize("d,nbits", [(128, 256), (256, 512), (64, 64), (48, 128)])
+@pytest.mark.parametrize("d,nbits", [(128, 256), (256, 512), (64, 64), (48, 128), (64, 2048), (40, 1312)])   # beyond 1024 bits / not 32 * 2^j bits: the L2-over-signs path
 def test_lsh_codes_and_search_bit_exact(d, nbits):
     from oracle import c_oracle as co
     from utils.nearest_neighbors import LSHIndex, lsh_rotation_matrix

@@ -228,8 +228,6 @@ def test_error_paths_raise_loudly():
         dense.linear(torch.zeros(4, 8), torch.zeros(3, 8))          # host tensors are not device pointers
     with pytest.raises(ValueError):
         dense.linear(torch.zeros(4, 8, device="cuda"), torch.zeros(3, 7, device="cuda"))
-    with pytest.raises(ValueError):
-        LSHIndex(16, 2048, 16)                                      # > 1024 bits
     idx = LSHIndex(16, 64, 16)
     idx.build(torch.randn(10, 16))
     with pytest.raises(AssertionError):
