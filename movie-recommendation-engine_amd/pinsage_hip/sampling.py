@@ -241,11 +241,18 @@ def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0,
             uoff, uniforms, mode = None, None, nv.PS_RNG_PHILOX
         else:
             raise ValueError("rng must be 'numpy' or 'philox'")
-        nv.call("ps_walk_sample_layers", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
-                nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T), nv.i32(mode), nv.ptr(uniforms), nv.ptr(uoff),
-                nv.i64(stride), nv.u64(seed & (2 ** 64 - 1)), nv.u32(call), nv.ptr(graph.nodeinfo), nv.ptr(graph.guide),
-                nv.ptr(graph.packed), nv.ptr(getattr(graph, "buckets", None)), nv.i32(layers), nv.ptr(ids), nv.ptr(counts),
-                nv.ptr(nvalid), nv.stream())
+        # one launch samples up to eight layers of a start node in one wave; deeper models take further launches over the
+        # next layers' calls / stream positions (same results: the layers are independent draws)
+        for r0 in range(0, layers, 8):
+            n = min(8, layers - r0)
+            u = uniforms
+            if uniforms is not None and r0:
+                u = uniforms[2 * r0 * stride:] if mode == nv.PS_RNG_STREAM_RAW else uniforms[r0 * stride:]
+            nv.call("ps_walk_sample_layers", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
+                    nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T), nv.i32(mode), nv.ptr(u), nv.ptr(uoff),
+                    nv.i64(stride), nv.u64(seed & (2 ** 64 - 1)), nv.u32(call + r0), nv.ptr(graph.nodeinfo), nv.ptr(graph.guide),
+                    nv.ptr(graph.packed), nv.ptr(getattr(graph, "buckets", None)), nv.i32(n), nv.ptr(ids[r0:r0 + n]),
+                    nv.ptr(counts[r0:r0 + n]), nv.ptr(nvalid[r0:r0 + n]), nv.stream())
     return [NeighborBatch(ids[r], counts[r], nvalid[r]) for r in range(layers)]
 
 

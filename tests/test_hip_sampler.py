@@ -334,7 +334,7 @@ def test_integration_md_ctypes_stub_reproduces_the_golden(golden):
         assert (cnt[i, :k] / cnt[i, :k].sum()).tolist() == g[pre + "weights"][i, :k].tolist()
 
 
-@pytest.mark.parametrize("W,L,T,layers", [(100, 2, 10, 2), (100, 2, 50, 3), (10, 3, 5, 2), (130, 1, 7, 4)])
+@pytest.mark.parametrize("W,L,T,layers", [(100, 2, 10, 2), (100, 2, 50, 3), (10, 3, 5, 2), (130, 1, 7, 4), (20, 2, 5, 11)])   # 11 layers: two launches
 def test_fused_layer_sampling_equals_separate_calls(W, L, T, layers):
     """ps_walk_sample_layers (all GCN layers' samples of a node in one wave; model/pinsage.py:271-275 draws them as
     consecutive batch_sample_neighbors calls) vs `layers` separate launches, in both RNG modes: ids, counts, nvalid
