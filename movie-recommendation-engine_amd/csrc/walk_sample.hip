@@ -320,7 +320,9 @@ extern "C" int ps_debug_ws_trace(unsigned long long *host) {
 constexpr int WAVES_PER_BLOCK = 1;   // one start node per workgroup: the dispatcher load-balances uneven nodes
 constexpr int BITMAP_WORDS = 40;   // counts <= 1024 -> 33 words, padded (larger W * L: WalkArgs::bitmap_words)
 
-template <int NP>
+// STREAM: compiled per RNG mode (the Philox variant carries no stream addressing, the stream variant no Philox state:
+// 83-85 VGPRs instead of 90 for both in one kernel, which is what leaves room for the up-front uniform loads below)
+template <int NP, bool STREAM>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkArgs a) {
     extern __shared__ int32_t smem[];
     const int lane = threadIdx.x & 63;
@@ -353,7 +355,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             continue;
         }
         PS_WS_STAMP(0);
-        const bool stream = a.rng_mode != PS_RNG_PHILOX, raw = a.rng_mode == PS_RNG_STREAM_RAW;
+        constexpr bool stream = STREAM;
+        const bool raw = a.rng_mode == PS_RNG_STREAM_RAW;
         const int64_t ubase0 = stream ? uniform_i64(a.uoff[i]) : 0;
 
         // ---------------- walk phase: all rounds, the start row is staged once ----------
@@ -381,6 +384,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             bool aliveA = actA, aliveB = actB;
             int32_t curA = (int32_t)s, curB = (int32_t)s;
             double uA1 = 2.0, uB1 = 2.0;
+            // stream mode, raw words, L = 2 (the reference's default walk): the four words of a walk's two uniforms are one
+            // aligned 16-byte load, requested before the walk starts (uoff is a multiple of W * L, so 2 w is even)
+            const bool pre = stream && raw && a.L == 2;
+            uint4 pwA = make_uint4(0u, 0u, 0u, 0u), pwB = pwA;
+            if (pre) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(a.uniforms);
+                if (actA) pwA = src[(ubase >> 1) + wA];
+                if (actB) pwB = src[(ubase >> 1) + wB];
+            }
             for (int st = 0; st < a.L; ++st) {
                 eidx_t loA = lo0, hiA = hi0, loB = lo0, hiB = hi0;
                 if (st > 0) {
@@ -391,8 +403,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                 if (hiB == loB) aliveB = false;
                 double uA = 2.0, uB = 2.0;
                 if (stream) {
-                    if (aliveA) uA = stream_uniform(a.uniforms, ubase + (int64_t)wA * a.L + st, raw);
-                    if (aliveB) uB = stream_uniform(a.uniforms, ubase + (int64_t)wB * a.L + st, raw);
+                    if (pre) {
+                        const uint32_t a0 = st ? pwA.z : pwA.x, a1 = st ? pwA.w : pwA.y, b0 = st ? pwB.z : pwB.x, b1 = st ? pwB.w : pwB.y;
+                        if (aliveA) uA = ((double)(mt_temper(a0) >> 5) * 67108864.0 + (double)(mt_temper(a1) >> 6)) * (1.0 / 9007199254740992.0);
+                        if (aliveB) uB = ((double)(mt_temper(b0) >> 5) * 67108864.0 + (double)(mt_temper(b1) >> 6)) * (1.0 / 9007199254740992.0);
+                    } else {
+                        if (aliveA) uA = stream_uniform(a.uniforms, ubase + (int64_t)wA * a.L + st, raw);
+                        if (aliveB) uB = stream_uniform(a.uniforms, ubase + (int64_t)wB * a.L + st, raw);
+                    }
                 } else if ((st & 1) == 0) {
                     philox_uniform2(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wA, (uint32_t)(st >> 1), call, uA, uA1);
                     philox_uniform2(a.seed_lo, a.seed_hi, (uint32_t)s, (uint32_t)wB, (uint32_t)(st >> 1), call, uB, uB1);
@@ -652,12 +670,17 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
             int dv = 0;                                                                                                        \
             if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= 64) return PS_ELAUNCH;                                      \
             if (!done[dv]) {                                                                                                   \
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(walk_sample_kernel<NP_>),                               \
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(walk_sample_kernel<NP_, false>),                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||               \
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(walk_sample_kernel<NP_, true>),                         \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PS_ELAUNCH; \
                 done[dv] = true;                                                                                               \
             }                                                                                                                  \
         }                                                                                                                      \
-        hipLaunchKernelGGL(walk_sample_kernel<NP_>, dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a);             \
+        if (rng_mode == PS_RNG_PHILOX)                                                                                         \
+            hipLaunchKernelGGL((walk_sample_kernel<NP_, false>), dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((walk_sample_kernel<NP_, true>), dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a);  \
     } while (0)
     switch (np) {
         case 1: PS_WS_LAUNCH(1); break;
