@@ -141,6 +141,170 @@ __device__ __forceinline__ void stash_item(float *d, f32x4 lo, f32x4 hi) {
 // FAST: every operand is 16-B aligned with K % BK == 0 -> unconditional float4 loads (rows past the end are
 // clamped to the last valid row; their results are never stored), so nothing branches or waits inside the
 // fetch and the loads stay in flight under the MFMAs.  The general variant predicates every element.
+// The epilogue of a block tile (bias / ReLU / fused row L2 norm / stores, or the LSH sign + ballot bit-pack), shared by the one-tile
+// kernel and the persistent kernel below.  C layout (32x32 tile): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+template <int WM, int WN, int TM, int TN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[TM][TN], int64_t m0, int n0, float *sRed, float *sNrm) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN, li = lane & 31, lh = lane >> 5;
+    (void)BN; (void)wv;
+    PS_TRACE(40);
+    // ------------------------------ epilogue -------------------------------------------------
+    // C layout (32x32 tile): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (EPI == 1) {
+        uint32_t *codes32 = reinterpret_cast<uint32_t *>(g.codes);
+        const int words = g.cs >> 2;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int colbase = n0 + (wn * TN + b) * 32;
+                const bool col_ok = colbase + li < g.N;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t mask = __ballot(col_ok && acc[a][b][r] >= 0.f);   // bit = (xt >= 0)
+                    const int64_t row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (li == 0 && row < g.M && colbase < g.N)
+                        codes32[row * words + (colbase >> 5)] = lh ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+                }
+            }
+        PS_TRACE(41);
+        return;
+    }
+
+    const bool relu = (g.flags & PS_RELU) && !(PS_GEMM_DEBUG & 8), l2 = (g.flags & PS_L2NORM) && !(PS_GEMM_DEBUG & 8);
+    if (PS_GEMM_DEBUG & 32) {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+        if (s == 12345.678f) g.y[0] = s;
+        PS_TRACE(41);
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + (wn * TN + b) * 32 + li;
+        const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[a][b][r] + bv;
+                if (relu) v = v > 0.f ? v : 0.f;
+                if (col >= g.N) v = 0.f;
+                acc[a][b][r] = v;
+            }
+    }
+    PS_TRACE(42);
+    if (l2) {   // F.normalize(p=2, dim=1, eps=1e-12): x / max(||x||, eps); the block holds whole rows
+        float ss[TM * 16];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = 0.f;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) t = fmaf(acc[a][b][r], acc[a][b][r], t);
+                ss[a * 16 + r] = t;
+            }
+        const float tot = transpose_sum32<TM * 16>(ss, lane);               // this wave's columns of ONE row per lane:
+        {                                                                   // idx bits = the butterfly's predicates
+            const int idx = ((lane ^ (lane >> 2)) & 1) | (((lane >> 1) ^ (lane >> 2)) & 1) << 1 | (((lane >> 2) ^ (lane >> 3)) & 1) << 2 |
+                            (lane & 8) | (TM == 2 ? lane & 16 : 0);
+            const int a = idx >> 4, r = idx & 15;
+            const int rowl = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (TM == 2 || li < 16) sRed[rowl * WN + wn] = tot;
+        }
+        PS_TRACE(43);
+        __syncthreads();
+        // one thread per row: norm, its correctly rounded reciprocal, the fast path's guard (see below)
+        for (int row = tid; row < BM; row += NT) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) t += sRed[row * WN + w];
+            float nrm = sqrtf(t);
+            nrm = nrm > 1e-12f ? nrm : 1e-12f;
+            const bool tame = nrm >= 0x1p-40f && nrm <= 0x1p40f;
+            *reinterpret_cast<f32x4 *>(sNrm + row * 4) = f32x4{nrm, 1.0f / nrm, nrm * 0x1p-60f, tame ? 0.f : 1.f};
+        }
+        __syncthreads();
+        PS_TRACE(44);
+        // x / nrm, IEEE-exact, without 64 v_div sequences per lane (11 instructions each; the epilogue was 22 % of a block's
+        // life, tools/gemm_trace.py): with y = RN(1 / nrm), q0 = x y is within 1.5 ulp, q1 = q0 + (x - nrm q0) y is a faithful
+        // quotient and q2 = q1 + (x - nrm q1) y is the correctly rounded one (Markstein's theorem; the remainders are exact
+        // in an fma) -- as long as nothing underflows on the way: the row's norm in [2^-40, 2^40] and x = +0 or
+        // |x| >= 2^-60 nrm.  A wave that sees anything else divides the ordinary way (tools/ubench/div_check.hip counts
+        // mismatches of the fast path against a / b: none in 6.9e10 pairs, half of them next to rounding boundaries).
+        bool wild = false;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 nr = *reinterpret_cast<const f32x4 *>(sNrm + ((wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4);
+                wild |= nr[3] != 0.f;
+#pragma unroll
+                for (int b = 0; b < TN; ++b)                      // -0 counts as nonzero: the corrections would return +0
+                    wild |= __float_as_uint(acc[a][b][r]) != 0u && !(fabsf(acc[a][b][r]) >= nr[2]);
+            }
+        if (__builtin_amdgcn_ballot_w64(wild) == 0) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 nr = *reinterpret_cast<const f32x4 *>(sNrm + ((wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4);
+                    const float nrm = nr[0], y = nr[1];
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const float x = acc[a][b][r];
+                        const float q0 = x * y, q1 = fmaf(fmaf(-nrm, q0, x), y, q0);
+                        acc[a][b][r] = fmaf(fmaf(-nrm, q1, x), y, q1);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float nrm = sNrm[((wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4];
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b][r] = acc[a][b][r] / nrm;
+                }
+        }
+    }
+    PS_TRACE(45);
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);     // block-uniform: no per-element guards
+    if (interior) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *dst = g.y + (m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * g.N + n0 + wn * TN * 32 + li;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) dst[b * 32] = acc[a][b][r];
+            }
+        PS_TRACE(41);
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row >= g.M) continue;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = n0 + (wn * TN + b) * 32 + li;
+                if (col < g.N) g.y[row * g.N + col] = acc[a][b][r];
+            }
+        }
+    PS_TRACE(41);
+}
+
 template <int WM, int WN, int TM, int TN, int BK, int EPI, bool FAST>
 #ifndef PS_GEMM_OCC
 #define PS_GEMM_OCC 2      // two blocks per CU (<= 256 VGPR + AGPR): one block's barriers and epilogue under the other's MFMAs
@@ -312,160 +476,134 @@ __global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(Gem
         }
     }
 
-    PS_TRACE(40);
-    // ------------------------------ epilogue -------------------------------------------------
-    // C layout (32x32 tile): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if (EPI == 1) {
-        uint32_t *codes32 = reinterpret_cast<uint32_t *>(g.codes);
-        const int words = g.cs >> 2;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int colbase = n0 + (wn * TN + b) * 32;
-                const bool col_ok = colbase + li < g.N;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint64_t mask = __ballot(col_ok && acc[a][b][r] >= 0.f);   // bit = (xt >= 0)
-                    const int64_t row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (li == 0 && row < g.M && colbase < g.N)
-                        codes32[row * words + (colbase >> 5)] = lh ? (uint32_t)(mask >> 32) : (uint32_t)mask;
-                }
-            }
-        PS_TRACE(41);
-        return;
-    }
+    gemm_epilogue<WM, WN, TM, TN, EPI>(g, acc, m0, n0, sRed, sNrm);
+}
 
-    const bool relu = (g.flags & PS_RELU) && !(PS_GEMM_DEBUG & 8), l2 = (g.flags & PS_L2NORM) && !(PS_GEMM_DEBUG & 8);
-    if (PS_GEMM_DEBUG & 32) {
-        float s = 0.f;
+// ------------------------------------------------------------------------------------------------------------
+// gemm_f32_pkernel: the same block tile, LDS image, MFMA stream and epilogue as gemm_f32_kernel<..., FAST = true>, as a
+// PERSISTENT kernel: a workgroup walks the tiles b, b + gridDim.x, ... and treats a tile boundary (and the boundary between
+// the two operand pairs of a layer GEMM) like a K-step boundary -- the first slab of the NEXT tile is requested during the last
+// MFMA step of the current one, so the global-load latency in front of a tile's first MFMA, which the one-tile kernel pays per
+// block, is paid once per workgroup.  Aligned operands only (16-byte rows, K % 32 == 0).  Arithmetic unchanged: one
+// accumulator per output, k ascending.
+template <int WM, int WN, int TM, int TN, int BK, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_pkernel(GemmArgs g, int tiles_n, int ntiles) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+    constexpr bool SPREAD = PS_GEMM_SPREAD && TM * TN >= 4;
+    constexpr int GRP = BK / 8;
+    constexpr int LDS_STRIDE = BK + 4;
+    constexpr int A_ITEMS = (BM * GRP + NT - 1) / NT, B_ITEMS = (BN * GRP + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_STRIDE + BM * WN + BM * 4];
+    float *sA = smem, *sB = smem + BM * LDS_STRIDE, *sRed = smem + (BM + BN) * LDS_STRIDE, *sNrm = sRed + BM * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int steps0 = g.K / BK, steps1 = g.x2 != nullptr ? g.K2 / BK : 0, nsteps = steps0 + steps1;
+
+    f32x4 ra[A_ITEMS][2], rb[B_ITEMS][2];
+    // slab s of the tile at (m0, n0): K step s of the first operand pair, or s - steps0 of the second
+    auto fetch = [&](int64_t m0, int n0, int s) __attribute__((always_inline)) {
+        const bool second = s >= steps0;
+        const float *X = second ? g.x2 : g.x;
+        const float *Wp = second ? g.W2 : g.W;
+        const int K = second ? g.K2 : g.K, ldw = second ? g.ldw2 : g.ldw;
+        const int k0 = (second ? s - steps0 : s) * BK;
+#pragma unroll
+        for (int q = 0; q < A_ITEMS; ++q) {
+            const int it = (tid + NT * q) % (BM * GRP), row = it / GRP, grp = it % GRP;
+            const int64_t m = m0 + row;
+            const float *src = X + (m < g.M ? m : g.M - 1) * K + k0 + grp * 8;
+            ra[q][0] = *reinterpret_cast<const f32x4 *>(src);
+            ra[q][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < B_ITEMS; ++q) {
+            const int it = (tid + NT * q) % (BN * GRP), row = it / GRP, grp = it % GRP;
+            const int n = n0 + row;
+            const float *src = Wp + (int64_t)(n < g.N ? n : g.N - 1) * ldw + k0 + grp * 8;
+            rb[q][0] = *reinterpret_cast<const f32x4 *>(src);
+            rb[q][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+        }
+    };
+    auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < A_ITEMS; ++q) {
+            const int it = (tid + NT * q) % (BM * GRP), row = it / GRP, grp = it % GRP;
+            stash_item<SPREAD>(sA + row * LDS_STRIDE + grp * 8, ra[q][0], ra[q][1]);
+        }
+#pragma unroll
+        for (int q = 0; q < B_ITEMS; ++q) {
+            const int it = (tid + NT * q) % (BN * GRP), row = it / GRP, grp = it % GRP;
+            stash_item<SPREAD>(sB + row * LDS_STRIDE + grp * 8, rb[q][0], rb[q][1]);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int64_t m0 = (int64_t)(tile / tiles_n) * BM;
+    int n0 = (tile % tiles_n) * BN;
+    fetch(m0, n0, 0);
+    while (true) {
+        const int next = tile + (int)gridDim.x;
+        const bool more = next < ntiles;                     // block-uniform
+        const int64_t m0n = more ? (int64_t)(next / tiles_n) * BM : m0;
+        const int n0n = more ? (next % tiles_n) * BN : n0;
+        f32x16 acc[TM][TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[a][b][r];
-        if (s == 12345.678f) g.y[0] = s;
-        PS_TRACE(41);
-        return;
-    }
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int col = n0 + (wn * TN + b) * 32 + li;
-        const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[a][b][r] + bv;
-                if (relu) v = v > 0.f ? v : 0.f;
-                if (col >= g.N) v = 0.f;
-                acc[a][b][r] = v;
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int s = 0; s < nsteps; ++s) {
+            __syncthreads();                                  // previous step's fragment reads are done
+            stash();
+            __syncthreads();
+            // the next slab: of this tile, or the first one of the workgroup's next tile, or (nothing left) this one again --
+            // always a fetch, so that the loads, the fragment reads and the MFMAs of a step are ONE basic block
+            {
+                const bool last = s + 1 >= nsteps;
+                fetch(last ? m0n : m0, last ? n0n : n0, last ? (more ? 0 : s) : s + 1);
             }
-    }
-    PS_TRACE(42);
-    if (l2) {   // F.normalize(p=2, dim=1, eps=1e-12): x / max(||x||, eps); the block holds whole rows
-        float ss[TM * 16];
+            f32x4 fa[2][TM], fb[2][TN];
+            auto frags = [&](int grp, int sl) __attribute__((always_inline)) {
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+                for (int a = 0; a < TM; ++a)
+                    fa[sl][a] = *reinterpret_cast<const f32x4 *>(sA + ((wm * TM + a) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float t = 0.f;
+                for (int b = 0; b < TN; ++b)
+                    fb[sl][b] = *reinterpret_cast<const f32x4 *>(sB + ((wn * TN + b) * 32 + li) * LDS_STRIDE + grp * 8 + lh * 4);
+            };
+            frags(0, 0);
 #pragma unroll
-                for (int b = 0; b < TN; ++b) t = fmaf(acc[a][b][r], acc[a][b][r], t);
-                ss[a * 16 + r] = t;
+            for (int grp = 0; grp < GRP; ++grp) {
+                const int sl = grp & 1;
+                if (grp + 1 < GRP) frags(grp + 1, sl ^ 1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][a][t], fb[sl][b][t], acc[a][b], 0, 0, 0);
             }
-        const float tot = transpose_sum32<TM * 16>(ss, lane);               // this wave's columns of ONE row per lane:
-        {                                                                   // idx bits = the butterfly's predicates
-            const int idx = ((lane ^ (lane >> 2)) & 1) | (((lane >> 1) ^ (lane >> 2)) & 1) << 1 | (((lane >> 2) ^ (lane >> 3)) & 1) << 2 |
-                            (lane & 8) | (TM == 2 ? lane & 16 : 0);
-            const int a = idx >> 4, r = idx & 15;
-            const int rowl = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (TM == 2 || li < 16) sRed[rowl * WN + wn] = tot;
-        }
-        PS_TRACE(43);
-        __syncthreads();
-        // one thread per row: norm, its correctly rounded reciprocal, the fast path's guard (see below)
-        for (int row = tid; row < BM; row += NT) {
-            float t = 0.f;
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
-            for (int w = 0; w < WN; ++w) t += sRed[row * WN + w];
-            float nrm = sqrtf(t);
-            nrm = nrm > 1e-12f ? nrm : 1e-12f;
-            const bool tame = nrm >= 0x1p-40f && nrm <= 0x1p40f;
-            *reinterpret_cast<f32x4 *>(sNrm + row * 4) = f32x4{nrm, 1.0f / nrm, nrm * 0x1p-60f, tame ? 0.f : 1.f};
-        }
-        __syncthreads();
-        PS_TRACE(44);
-        // x / nrm, IEEE-exact, without 64 v_div sequences per lane (11 instructions each; the epilogue was 22 % of a block's
-        // life, tools/gemm_trace.py): with y = RN(1 / nrm), q0 = x y is within 1.5 ulp, q1 = q0 + (x - nrm q0) y is a faithful
-        // quotient and q2 = q1 + (x - nrm q1) y is the correctly rounded one (Markstein's theorem; the remainders are exact
-        // in an fma) -- as long as nothing underflows on the way: the row's norm in [2^-40, 2^40] and x = +0 or
-        // |x| >= 2^-60 nrm.  A wave that sees anything else divides the ordinary way (tools/ubench/div_check.hip counts
-        // mismatches of the fast path against a / b: none in 6.9e10 pairs, half of them next to rounding boundaries).
-        bool wild = false;
+            for (int grp = 0; grp < GRP; ++grp) {
+                if (grp + 1 < GRP) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const f32x4 nr = *reinterpret_cast<const f32x4 *>(sNrm + ((wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4);
-                wild |= nr[3] != 0.f;
-#pragma unroll
-                for (int b = 0; b < TN; ++b)                      // -0 counts as nonzero: the corrections would return +0
-                    wild |= __float_as_uint(acc[a][b][r]) != 0u && !(fabsf(acc[a][b][r]) >= nr[2]);
-            }
-        if (__builtin_amdgcn_ballot_w64(wild) == 0) {
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const f32x4 nr = *reinterpret_cast<const f32x4 *>(sNrm + ((wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4);
-                    const float nrm = nr[0], y = nr[1];
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) {
-                        const float x = acc[a][b][r];
-                        const float q0 = x * y, q1 = fmaf(fmaf(-nrm, q0, x), y, q0);
-                        acc[a][b][r] = fmaf(fmaf(-nrm, q1, x), y, q1);
-                    }
+                for (int t = 0; t < 4; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                    if (SPREAD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
-        } else {
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float nrm = sNrm[((wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4];
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) acc[a][b][r] = acc[a][b][r] / nrm;
-                }
-        }
-    }
-    PS_TRACE(45);
-    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);     // block-uniform: no per-element guards
-    if (interior) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float *dst = g.y + (m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * g.N + n0 + wn * TN * 32 + li;
-#pragma unroll
-                for (int b = 0; b < TN; ++b) dst[b * 32] = acc[a][b][r];
-            }
-        PS_TRACE(41);
-        return;
-    }
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row >= g.M) continue;
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int col = n0 + (wn * TN + b) * 32 + li;
-                if (col < g.N) g.y[row * g.N + col] = acc[a][b][r];
             }
         }
-    PS_TRACE(41);
+        gemm_epilogue<WM, WN, TM, TN, EPI>(g, acc, m0, n0, sRed, sNrm);
+        if (!more) break;
+        tile = next;
+        m0 = m0n;
+        n0 = n0n;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -685,8 +823,50 @@ __global__ void l2norm_rows_kernel(float *y, int64_t M, int N) {   // N > 256 on
     }
 }
 
+// workgroups a persistent launch keeps resident: the occupancy of the instantiation x the CUs of the device (cached)
+template <typename K>
+int persistent_slots(K kernel) {
+    static int slots[64] = {};
+    int dv = 0;
+    if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= 64) return 0;
+    if (slots[dv] == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dv) != hipSuccess || cus <= 0) return 0;
+        slots[dv] = per_cu * cus;
+    }
+    return slots[dv];
+}
+
+template <int WM, int WN, int TM, int TN, int EPI>
+int launch_persistent(const GemmArgs &g, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int64_t tiles_m = ps_cdiv(g.M, BM);
+    const int tiles_n = (int)ps_cdiv(g.N, BN);
+    const int64_t ntiles = tiles_m * tiles_n;
+    if (ntiles > 0x7fffffff) return PS_EUNSUPPORTED;
+    const int slots = persistent_slots(gemm_f32_pkernel<WM, WN, TM, TN, 32, EPI>);
+    if (slots <= 0) return PS_ELAUNCH;
+    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    hipLaunchKernelGGL((gemm_f32_pkernel<WM, WN, TM, TN, 32, EPI>), dim3(grid), dim3(256), 0, st, g, tiles_n, (int)ntiles);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
 template <int EPI, bool FAST>
 int launch_gemm_v(const GemmArgs &g, hipStream_t st) {
+    // aligned operands: the persistent form of the same tiles (PS_GEMM_PERSIST=0: the one-tile-per-workgroup kernels)
+    if (FAST && g.grp == nullptr && g.N > 128 && (g.x2 == nullptr || g.K2 % 32 == 0)) {
+        const char *pe = getenv("PS_GEMM_PERSIST");
+        const bool persist = pe == nullptr || atoi(pe) != 0;
+        if (persist) {
+            // measured r03 (tools/gemm_probe.py --env PS_GEMM_PERSIST=0,1, M = 59 047 / 10 000): 64 x 128 tiles +2-3 % / +9 %,
+            // 32 x 256 tiles (small M, fused norm) +7-9 %; the 64 x 256 fused-norm tile does not fit the registers in this form
+            // (256 VGPRs, 35 spilled: 103 -> 92 TFLOP/s) and keeps the one-tile kernel
+            if (!(g.flags & PS_L2NORM)) return launch_persistent<2, 2, 1, 2, EPI>(g, st);
+            if (g.M < 64 * 384) return launch_persistent<1, 4, 1, 2, EPI>(g, st);
+        }
+    }
     if (g.N <= 64) {
         dim3 grid((unsigned)ps_cdiv(g.M, 64), 1);
         hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 1, 1, 32, EPI, FAST>), grid, dim3(256), 0, st, g);
