@@ -141,19 +141,22 @@ int ps_uniform_offsets(const int64_t *rowptr, int64_t V, const int64_t *starts, 
  * the parallel path (2^c-word chunks, c = ps_mt19937_chunk_log2(), generated by independent workgroups, windows by
  * jump-ahead); with NULL polynomials / workspace a single workgroup generates the stream serially (skip must be 0).
  * radix_polys uint32[radix_levels, 31, 624] (entry (i, j-1) = t^(j * 2^(c + 5i)) mod phi, optional): the chunk windows
- * are then produced in radix-32 rounds instead of by doubling. */
+ * are then produced in radix-32 rounds instead of by doubling.
+ * window_polys uint32[n_window, 624] (row j-1 = t^(j * 2^c) mod phi, optional; mtjump.window_polynomials): requests of
+ * 33 .. n_window + 1 chunks get ALL their windows in one product round from the first window. */
 /* ps_mt19937_raw_stream: the same stream (skip = 0) left as untempered 32-bit state words in raw uint32[2n + 1248] for
  * PS_RNG_STREAM_RAW -- the walk kernel tempers and combines the two words of a uniform itself, which saves the conversion
  * pass (65 us and 190 MB of traffic per 23.6 M doubles).  Needs the jump polynomials (n >= 2^17). */
 int ps_mt19937_chunk_log2(void);
 int ps_mt19937_raw_stream(const uint32_t *state_in, int pos_in, int64_t n, uint32_t *raw, uint32_t *state_out,
                           int32_t *pos_out, const uint32_t *jump_polys, int jump_levels, const uint32_t *radix_polys,
-                          int radix_levels, void *workspace, size_t workspace_bytes, ps_stream_t stream);
+                          int radix_levels, const uint32_t *window_polys, int n_window, void *workspace,
+                          size_t workspace_bytes, ps_stream_t stream);
 size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n);
 int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,
                              uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys, int jump_levels,
-                             const uint32_t *radix_polys, int radix_levels, void *workspace, size_t workspace_bytes,
-                             ps_stream_t stream);
+                             const uint32_t *radix_polys, int radix_levels, const uint32_t *window_polys, int n_window,
+                             void *workspace, size_t workspace_bytes, ps_stream_t stream);
 
 /* ---- a5 / a9: ImportancePooling.forward (model/pinsage.py:101-150); Weighted/Mean/Importance
  * aggregators' gather + weighted reduce (model/aggregators.py:13-91,233-287).

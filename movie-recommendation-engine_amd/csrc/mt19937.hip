@@ -20,7 +20,7 @@
 
 #ifndef PS_MT_DEBUG
 #define PS_MT_DEBUG 0     // knock-outs (tools/mt_knockout.sh; wrong results): jump product 1 no nibble-stream build, 2 A operands
-#endif                    // loaded once, 4 no parity epilogue, 8 no MFMA; chunk generator 16 no stores, 32 no barrier
+#endif                    // loaded once, 4 no parity epilogue, 8 no MFMA, 64 Hankel fragments loaded once; chunk generator 16 no stores, 32 no barrier
 
 namespace {
 
@@ -80,6 +80,48 @@ __device__ __forceinline__ void next_block_emit(const uint32_t *o, uint32_t *n, 
             const int i3 = t < 169 ? 454 + t : 623;
             n[i3] = c;
             emit(i3, c);
+        }
+    }
+    if (!(PS_MT_DEBUG & 32)) __syncthreads();
+}
+
+// The recurrence run BACKWARDS: x[k+624] ^ x[k+397] = twist(x[k], x[k+1]) is invertible -- the top bit of the left side says
+// whether the magic constant went in (= low bit of x[k+1]) -- and yields y(k) = (top bit of x[k]) | (low 31 bits of x[k+1]), so
+// x[k] = top(y(k)) | low(y(k-1)).
+__device__ __forceinline__ uint32_t untwist(uint32_t tmp) {
+    const uint32_t m = (uint32_t)((int32_t)tmp >> 31);                       // all ones when the magic constant went in
+    return __builtin_amdgcn_alignbit(tmp ^ (m & 0x9908b0dfu), tmp, 31);      // ((..) << 1) | (tmp >> 31): four instructions
+}
+
+// previous 624 words from a block (o = x[n .. n+623] -> p = x[n-624 .. n-1]), ONE barrier and NO dependency inside the block:
+// with Y(i) = y(n - 624 + i) = untwist(o[i] ^ (i >= 227 ? o[i - 227] : p[i + 397])) and p[i] = top(Y(i)) | low(Y(i - 1)),
+//   p[i], i >= 228   needs o[i], o[i-1], o[i-227], o[i-228] only;
+//   p[i], i = 1..226 needs p[i+397], p[i+396] -- both of the first kind -- and o[i], o[i-1];
+//   p[227] and p[0] need p[623] (Y(226) = untwist(o[226] ^ p[623]), Y(-1) = untwist(p[623] ^ p[396])), of the first kind too.
+// Thread t < 227 produces p[t + 397] and p[t] (recomputing p[t + 396] for itself: 9 old words), thread t < 170 also p[227 + t];
+// thread 0's two extra words are broadcast reads for everybody.
+template <typename Emit>
+__device__ __forceinline__ void prev_block_emit(const uint32_t *o, uint32_t *p, int t, Emit emit) {
+    constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu;
+    if (t < 227) {
+        const int tm = t > 0 ? t - 1 : 0, u = t < 170 ? t : 169;               // threads 170..226 re-read a valid pair they do not use
+        const uint32_t a0 = o[t + 395], a1 = o[t + 396], a2 = o[t + 397], b0 = o[t + 168], b1 = o[t + 169], b2 = o[t + 170];
+        const uint32_t c0 = o[tm], c1 = o[t], d0 = o[226 + u], d1 = o[227 + u], l622 = o[622], l623 = o[623];
+        const uint32_t y397 = untwist(a2 ^ b2), y396 = untwist(a1 ^ b1), y395 = untwist(a0 ^ b0);
+        const uint32_t n397 = (y397 & UP) | (y396 & LO);                       // p[t + 397]
+        const uint32_t n396 = (y396 & UP) | (y395 & LO);                       // p[t + 396]
+        uint32_t n623 = 0;
+        if (t == 0) n623 = (untwist(l623 ^ a1) & UP) | (untwist(l622 ^ a0) & LO);        // p[623] (a1 = o[396], a0 = o[395]); three of four waves skip it
+        const uint32_t ylo = untwist((t > 0 ? c0 : n623) ^ n396);              // Y(t - 1)
+        const uint32_t nt = (untwist(c1 ^ n397) & UP) | (ylo & LO);            // p[t]
+        p[t] = nt;
+        p[t + 397] = n397;
+        emit(t, nt);
+        emit(t + 397, n397);
+        if (t < 170) {
+            const uint32_t v = (untwist(d1 ^ c1) & UP) | (untwist(d0 ^ (t > 0 ? c0 : n623)) & LO);    // p[227 + t]
+            p[227 + t] = v;
+            emit(227 + t, v);
         }
     }
     if (!(PS_MT_DEBUG & 32)) __syncthreads();
@@ -249,8 +291,9 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 
 constexpr int KS_TOTAL = 315;                 // 64-bit k steps: 312 (19 968 polynomial bits) padded to a multiple of 5 x parts
 constexpr int PLW = SEQ_PAD / 32;             // dwords per bit plane of an expanded sequence
-constexpr int JT = 20, JG = 5;                // 32-lag tiles (624 lags = 19.5 tiles), lag tiles per work item
-static_assert(SEQ_PAD % 32 == 0 && JT * 32 >= MT_N && JT == 4 * JG, "plane geometry: four waves x JG lag tiles");
+constexpr int JT = 20, JG = 10;               // 32-lag tiles (624 lags = 19.5 tiles), lag tiles per wave
+constexpr int MF_PLANES = 2;                  // bit planes per workgroup (two waves each)
+static_assert(SEQ_PAD % 32 == 0 && JT * 32 >= MT_N && JT == 2 * JG && 32 % MF_PLANES == 0, "plane geometry: two waves x JG lag tiles");
 
 // 8 bits -> 8 fp4 nibbles (bit set -> 1.0 = 0x2), lowest bit in the lowest nibble
 __device__ __forceinline__ uint32_t bits_to_fp4(uint32_t byte) {
@@ -264,6 +307,47 @@ __global__ __launch_bounds__(256) void mt_pack_polys_kernel(const uint32_t *__re
     if (idx >= KS_TOTAL * 64) return;
     const int ks = idx >> 6, lane = idx & 63, m = lane & 31, w = 2 * ks + (lane >> 5);
     const uint32_t word = (m < rows && w < MT_N) ? polys[(size_t)m * MT_N + w] : 0u;
+    polyA[idx] = make_uint4(bits_to_fp4(word & 255u), bits_to_fp4((word >> 8) & 255u), bits_to_fp4((word >> 16) & 255u),
+                            bits_to_fp4(word >> 24));
+}
+
+// First launch of the one-round scheme.  Workgroup 0 (when `state_in` is given): the window W1 at stream word 1 and word 0 from
+// numpy's state (= mt_prepare_kernel), W1 to plain0, and its expansion to 34 blocks (= mt_expand_kernel) -- a serial chain of
+// 36 block updates; the other workgroups meanwhile expand `ngroups` 32-row groups of the window-polynomial table into MFMA A
+// operands (= mt_pack_polys_kernel per group; rows >= nrows: zero).
+__global__ __launch_bounds__(256) void mt_begin_kernel(const uint32_t *__restrict__ state_in, int pos_in, uint32_t *__restrict__ plain0,
+                                                       uint32_t *__restrict__ word0, uint32_t *__restrict__ seq,
+                                                       const uint32_t *__restrict__ polys, int nrows, int ngroups, uint4 *__restrict__ polyA) {
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0) {
+        if (state_in == nullptr) return;
+        __shared__ uint32_t s3[3 * MT_N];
+        __shared__ uint32_t mt[2][MT_N];
+        for (int i = t; i < MT_N; i += 256) s3[i] = state_in[i];
+        __syncthreads();
+        next_block(s3, s3 + MT_N, t);
+        next_block(s3 + MT_N, s3 + 2 * MT_N, t);
+        for (int i = t; i < MT_N; i += 256) {
+            const uint32_t v = s3[pos_in + 1 + i];
+            mt[0][i] = v;
+            plain0[i] = v;
+            seq[i] = v;
+        }
+        if (t == 0) word0[0] = s3[pos_in];
+        __syncthreads();
+        int cur = 0;
+        for (int blk = 1; blk < 34; ++blk) {
+            uint32_t *dst = seq + blk * MT_N;
+            next_block_emit(mt[cur], mt[cur ^ 1], t, [&](int i, uint32_t v) { dst[i] = v; });
+            cur ^= 1;
+        }
+        return;
+    }
+    const int64_t idx = (int64_t)(blockIdx.x - 1) * 256 + t;
+    if (idx >= (int64_t)ngroups * KS_TOTAL * 64) return;
+    const int g = (int)(idx / (KS_TOTAL * 64)), rem = (int)(idx % (KS_TOTAL * 64));
+    const int ks = rem >> 6, lane = rem & 63, row = 32 * g + (lane & 31), w = 2 * ks + (lane >> 5);
+    const uint32_t word = (row < nrows && w < MT_N) ? polys[(size_t)row * MT_N + w] : 0u;
     polyA[idx] = make_uint4(bits_to_fp4(word & 255u), bits_to_fp4((word >> 8) & 255u), bits_to_fp4((word >> 16) & 255u),
                             bits_to_fp4(word >> 24));
 }
@@ -293,66 +377,86 @@ __device__ __forceinline__ v16f_t bit_mfma(const v4i_t &a, const v4i_t &b, const
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
-// One workgroup = (source, bit plane b, slice `part` of the polynomial bits); its four waves take five lag tiles each and share
-// the nibble stream in LDS and -- through the L1 -- the A fragments.  PLp[part][src][b][J][lane] = the parities of this slice
-// as the MFMA leaves them: bit r of entry `lane` = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), lag 32 J + (lane & 31) (plain
-// stores: mt_jump_reduce_kernel XORs the slices, mt_jump_finish_kernel turns the bit planes into words).
+// One workgroup = (source, TWO bit planes, slice `part` of the polynomial bits); two waves per plane take ten lag tiles each:
+// a k step is 10 MFMAs for one A fragment (global, shared by the workgroup's waves through the L1) and two Hankel fragments
+// (LDS).  r03: five tiles per wave / four waves per plane asked for 51 B/clk of L1 and 102 B/clk of LDS per CU at the MFMA peak
+// -- 80 % of either path -- and ran at 49 % of the peak; ten tiles halve both.
+// PLp[part][src][b][J][lane] = the parities of this slice as the MFMA leaves them: bit r of entry `lane` = row
+// (r & 3) + 8 (r >> 2) + 4 (lane >> 5), lag 32 J + (lane & 31) (plain stores: mt_jump_reduce_kernel XORs the slices,
+// mt_jump_finish_kernel turns the bit planes into words).
+// `ngroups` > 1 (one-round windows): "source" src is the pair (real source src / ngroups, polynomial group src % ngroups) -- the
+// groups are 32-row blocks of one long polynomial table, all applied to the same planes.
 __global__ __launch_bounds__(256, 2) void mt_jump_mfma_kernel(const uint32_t *__restrict__ planes, const uint4 *__restrict__ polyA,
-                                                              uint16_t *__restrict__ PLp, int nsrc, int parts, int steps) {
-    extern __shared__ uint32_t copies[];                     // [8][CW]
-    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6, n = lane & 31, kb = lane >> 5;
+                                                              uint16_t *__restrict__ PLp, int nsrc, int parts, int steps, int ngroups) {
+    extern __shared__ uint32_t copies[];                     // [MF_PLANES][8][CW]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pb = wv >> 1, g = wv & 1, n = lane & 31, kb = lane >> 5;
     int item = blockIdx.x;
-    const int b = item & 31; item >>= 5;
+    const int b0 = (item % (32 / MF_PLANES)) * MF_PLANES; item /= (32 / MF_PLANES);
     const int src = item % nsrc, part = item / nsrc;
     const int ks0 = part * steps, J0 = g * JG;
     const int dmin = 2 * ks0;
     const int CW = 4 * (2 * steps + JT + 1) + 8;             // dwords per copy: fragments d = dmin .. dmin + 2 steps + JT
-    // nibble stream of plane b from nibble 32 dmin on, eight shifts
-    const uint32_t *pl = planes + ((size_t)src * 32 + b) * PLW;
-    for (int m = tid; m < ((PS_MT_DEBUG & 1) ? 64 : CW); m += 256) {
+    // nibble streams of the planes b0 .. from nibble 32 dmin on, eight shifts each
+    for (int mm = tid; mm < ((PS_MT_DEBUG & 1) ? 64 : MF_PLANES * CW); mm += 256) {
+        const int q = mm / CW, m = mm % CW;
+        const uint32_t *pl = planes + ((size_t)(src / ngroups) * 32 + b0 + q) * PLW;
+        uint32_t *cp = copies + (size_t)q * 8 * CW;
         const int p0 = 32 * dmin + 8 * m;                    // first plane bit of dword m (copy 0)
         const uint32_t w0 = (p0 >> 5) < PLW ? pl[p0 >> 5] : 0u, w1 = ((p0 + 8) >> 5) < PLW ? pl[(p0 + 8) >> 5] : 0u;
         const uint32_t e0 = bits_to_fp4((w0 >> (p0 & 31)) & 255u), e1 = bits_to_fp4((w1 >> ((p0 + 8) & 31)) & 255u);
-        copies[m] = e0;
+        cp[m] = e0;
 #pragma unroll
-        for (int c = 1; c < 8; ++c) copies[c * CW + m] = __builtin_amdgcn_alignbit(e1, e0, 4 * c);
+        for (int c = 1; c < 8; ++c) cp[c * CW + m] = __builtin_amdgcn_alignbit(e1, e0, 4 * c);
     }
     __syncthreads();
-    const uint32_t *frag = copies + (n & 7) * CW + 4 * (J0 + kb) + (n >> 3);       // + 4 x for R_{dmin + J0 + x}
+    const int b = b0 + pb;
+    const uint32_t *frag = copies + (size_t)pb * 8 * CW + (n & 7) * CW + 4 * (J0 + kb) + (n >> 3);       // + 4 x for R_{dmin + J0 + x}
     auto load_r = [&](int x) { const uint32_t *q = frag + 4 * x; return v4i_t{(int)q[0], (int)q[1], (int)q[2], (int)q[3]}; };
-    const uint4 *pa = polyA + (size_t)ks0 * 64 + lane;
-    auto load_a = [&](int u) { const uint4 v = pa[(size_t)u * 64]; return v4i_t{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; };
+    const uint4 *pa = polyA + ((size_t)(src % ngroups) * KS_TOTAL + ks0) * 64 + lane;
+    // A fragments are requested PF steps ahead by inline asm and awaited with COUNTED vmcnt (the loop holds no other vector-memory
+    // instruction): the compiler's own bookkeeping put `s_waitcnt vmcnt(0)` at the loop head, i.e. waited for the load it had just
+    // issued, once per PF steps
+    auto load_a = [&](v4i_t &dst, int u) {
+        const uint4 *ptr = pa + (size_t)u * 64;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+    };
 
     v16f_t acc[JG];
 #pragma unroll
     for (int j = 0; j < JG; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    constexpr int PF = 10;                                   // A fragments in flight (k steps ahead)
+    constexpr int PF = 5;                                    // A fragments in flight (k steps ahead; 2 PF must be a multiple of JG)
     v4i_t R[JG], A[PF];
 #pragma unroll
     for (int j = 0; j < JG; ++j) R[j] = load_r(j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the prologue's loads are done: from here on the count is the A ring's
 #pragma unroll
-    for (int u = 0; u < PF; ++u) A[u] = load_a(u < steps ? u : 0);
+    for (int u = 0; u < PF; ++u) load_a(A[u], u < steps ? u : 0);
+    // `steps` is a multiple of PF (host: 45 or 15) and the loop body has NO branch: a conditional A load became a phi with
+    // register copies behind `s_waitcnt vmcnt(0)` in every step (r03: 64 us for the 361 windows of a walk pass, the load latency
+    // exposed once per step) -- past the end the last fragment is loaded again and not used
     for (int ub = 0; ub < steps; ub += PF) {
 #pragma unroll
         for (int uu = 0; uu < PF; ++uu) {
-            if (ub + uu < steps) {                           // wave-uniform
-                // step u = ub + uu: lag tile jj uses R_{dmin + J0 + 2 u + jj} = slot (2 uu + jj) % JG (ub is a multiple of 5)
-                const v4i_t a = A[uu];
+            // step u = ub + uu: lag tile jj uses R_{dmin + J0 + 2 u + jj} = slot (2 uu + jj) % JG (2 ub is a multiple of JG)
+            static_assert(PF == 5, "vmcnt literal below = PF - 1");
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(A[uu]) : : "memory");       // PF - 1 younger requests may still be in flight
+            const v4i_t a = A[uu];
 #pragma unroll
-                for (int jj = 0; jj < JG; ++jj) {
-                    if (!(PS_MT_DEBUG & 8)) acc[jj] = bit_mfma(a, R[(2 * uu + jj) % JG], acc[jj]);
-                    else acc[jj][0] += __builtin_bit_cast(float, a[0] ^ R[(2 * uu + jj) % JG][0]);
-                    if (jj == 1) {    // slots 2 uu, 2 uu + 1 are free: the two fragments the next step adds (past the end: in range, unused)
-                        R[(2 * uu) % JG] = load_r(2 * (ub + uu) + JG);
-                        R[(2 * uu + 1) % JG] = load_r(2 * (ub + uu) + JG + 1);
-                    }
+            for (int jj = 0; jj < JG; ++jj) {
+                if (!(PS_MT_DEBUG & 8)) acc[jj] = bit_mfma(a, R[(2 * uu + jj) % JG], acc[jj]);
+                else acc[jj][0] += __builtin_bit_cast(float, a[0] ^ R[(2 * uu + jj) % JG][0]);
+                if (jj == 1 && !(PS_MT_DEBUG & 64)) {    // slots 2 uu, 2 uu + 1 are free: the two fragments the next step adds (past the end: in range, unused)
+                    R[(2 * uu) % JG] = load_r(2 * (ub + uu) + JG);
+                    R[(2 * uu + 1) % JG] = load_r(2 * (ub + uu) + JG + 1);
                 }
-                if (ub + PF + uu < steps && !(PS_MT_DEBUG & 2)) A[uu] = load_a(ub + PF + uu);
             }
+            { const int nx = ub + PF + uu; load_a(A[uu], (nx < steps && !(PS_MT_DEBUG & 2)) ? nx : steps - 1); }
+            __builtin_amdgcn_sched_barrier(0);               // the request stays HERE, PF steps ahead of its use
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the ring's last (unused) requests
     // parities: C col = lane & 31 (lag), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (polynomial).  Every lane packs the
     // parities of its 16 rows into 16 bits and stores them as they lie (one coalesced 128-byte store per lag tile);
     // mt_jump_finish_kernel picks bit r of lane (lag, row half) -- 16 ballots per tile cost 6 x the instructions
@@ -402,41 +506,67 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const uint32_t *parts, uin
     plain[i] = v;
 }
 
-// chunk c (window = states[c]) holds stream words [1 + (c0 + c) * CHUNK, +CHUNK); raw[w - w_lo] for w in [w_lo, w_hi)
-// A chunk is a serial chain of 210 block updates (LDS round trip + barrier each).  The loop is unrolled by two so that the
-// two LDS images have constant addresses, the block's position against [w_lo, w_hi) is scalar work, and the chain ends where
-// the wanted words end.  (Several chunks per workgroup behind common barriers were slower: 109 / 142 us for 2 / 4 against 99.)
+// Window c = states[c] = stream words [1 + (c0 + c) * CHUNK, + 624).  Its chunk is generated in BOTH directions by two
+// workgroups (blockIdx.y): forwards the words [wbase, wbase + HALF), backwards the words [wbase - HALF, wbase) -- a serial chain
+// of 105 block updates each (LDS round trip + barrier) instead of 210 for the same number of windows (r02: 72 us per chain).
+// raw[w - w_lo] for w in [w_lo, w_hi).  The loops are unrolled by two so that the two LDS images have constant addresses, a
+// block's position against the wanted range is scalar work, and a chain ends where the wanted words end.
+// (Several chunks per workgroup behind common barriers were slower: 109 / 142 us for 2 / 4 against 99.)
+constexpr int64_t HALF = CHUNK / 2;
+// The 624 words from key_w on are also the state numpy is left in: stored to state_out by whoever produces them (key_w < 1:
+// none here, mt_final_state_kernel copies them).
 __global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, int nparts, int64_t c0, int64_t w_lo,
-                                                       int64_t w_hi, uint32_t *raw) {
+                                                       int64_t w_hi, uint32_t *raw, int64_t key_w, uint32_t *state_out, int pos,
+                                                       int32_t *pos_out) {
     __shared__ uint32_t mt[2][MT_N];
     const int t = threadIdx.x;
+    const bool back = blockIdx.y != 0;
+    if (blockIdx.x == 0 && !back && t == 0 && key_w >= 1) pos_out[0] = pos;
     const int64_t wbase = 1 + (c0 + blockIdx.x) * CHUNK;
-    const int64_t end = (w_hi - wbase) < CHUNK ? (w_hi - wbase) : CHUNK;      // words of this chunk that anybody wants
-    auto put = [&](int64_t off, int i, uint32_t v) {          // word i of the block that starts `off` words into the chunk
-        const int64_t w = wbase + off + i;
-        if (off + i < end && w >= w_lo) raw[w - w_lo] = v;
+    // wanted words of this workgroup: [lo, hi)
+    int64_t lo = back ? wbase - HALF : wbase, hi = back ? wbase : wbase + HALF;
+    if (lo < w_lo) lo = w_lo;
+    if (lo < 1) lo = 1;
+    if (hi > w_hi) hi = w_hi;
+    if (lo >= hi) return;                                      // block-uniform
+    auto put = [&](int64_t w0, int i, uint32_t v) {            // word i of the block that starts at stream word w0
+        const int64_t w = w0 + i;
+        if (w >= lo && w < hi) {
+            raw[w - w_lo] = v;
+            if (w >= key_w && w < key_w + MT_N) state_out[w - key_w] = v;
+        }
     };
     for (int i = t; i < MT_N; i += 256) {
         const uint32_t v = load_window_word(states + (size_t)blockIdx.x * nparts * MT_N, nparts, i);
         mt[0][i] = v;
-        put(0, i, v);
+        if (!back) put(wbase, i, v);
     }
     __syncthreads();
-    auto step = [&](const uint32_t *o, uint32_t *n, int64_t off) {
-        const int64_t w0 = wbase + off;
-        if (off + MT_N <= end && w0 >= w_lo) {                 // whole block wanted (scalar test): no per-word tests
+    auto step = [&](const uint32_t *o, uint32_t *n, int64_t w0) {
+        if (w0 >= lo && w0 + MT_N <= hi && (w0 + MT_N <= key_w || w0 >= key_w + MT_N)) {   // whole block wanted, no state word in it (scalar test): no per-word tests
             uint32_t *dst = raw + (w0 - w_lo);
-            next_block_emit(o, n, t, [&](int i, uint32_t v) { if (!(PS_MT_DEBUG & 16) || v == 0x12345u) dst[i] = v; });
+            if (back) prev_block_emit(o, n, t, [&](int i, uint32_t v) { if (!(PS_MT_DEBUG & 16) || v == 0x12345u) dst[i] = v; });
+            else next_block_emit(o, n, t, [&](int i, uint32_t v) { if (!(PS_MT_DEBUG & 16) || v == 0x12345u) dst[i] = v; });
         } else {
-            next_block_emit(o, n, t, [&](int i, uint32_t v) { put(off, i, v); });
+            if (back) prev_block_emit(o, n, t, [&](int i, uint32_t v) { put(w0, i, v); });
+            else next_block_emit(o, n, t, [&](int i, uint32_t v) { put(w0, i, v); });
         }
     };
-    int64_t off = MT_N;
-    for (; off + MT_N < end; off += 2 * MT_N) {
-        step(mt[0], mt[1], off);
-        step(mt[1], mt[0], off + MT_N);
+    if (!back) {
+        int64_t w0 = wbase + MT_N;
+        for (; w0 + MT_N < hi; w0 += 2 * MT_N) {
+            step(mt[0], mt[1], w0);
+            step(mt[1], mt[0], w0 + MT_N);
+        }
+        if (w0 < hi) step(mt[0], mt[1], w0);
+    } else {
+        int64_t w0 = wbase - MT_N;                             // first word of the block being produced
+        for (; w0 > lo; w0 -= 2 * MT_N) {                      // a second block is wanted after this one
+            step(mt[0], mt[1], w0);
+            step(mt[1], mt[0], w0 - MT_N);
+        }
+        if (w0 + MT_N > lo) step(mt[0], mt[1], w0);
     }
-    if (off < end) step(mt[0], mt[1], off);
 }
 
 __global__ void mt_raw_to_double_kernel(const uint32_t *raw, int64_t w_lo, int64_t skip, int64_t n, double *out) {
@@ -478,9 +608,10 @@ Plan make_plan(int pos_in, int64_t skip, int64_t n) {
     if (p.key_w >= 0 && p.key_w < p.w_lo) p.w_lo = p.key_w;
     p.w_hi = p.wb;
     if (p.key_w >= 0 && p.key_w + MT_N > p.w_hi) p.w_hi = p.key_w + MT_N;
-    const int64_t first = p.w_lo < 1 ? 1 : p.w_lo;
-    p.c0 = (first - 1) / CHUNK;
-    p.c1 = (p.w_hi - 2) / CHUNK;
+    // window c serves the words [1 + c * CHUNK - HALF, 1 + c * CHUNK + HALF) (mt_chunk_kernel: both directions)
+    const int64_t first = p.w_lo < 1 ? 1 : p.w_lo, last = p.w_hi - 1;
+    p.c0 = (first - 1 + HALF) / CHUNK;
+    p.c1 = last >= 1 ? (last - 1 + HALF) / CHUNK : 0;
     if (p.c1 < p.c0) p.c1 = p.c0;
     return p;
 }
@@ -491,30 +622,31 @@ extern "C" int ps_mt19937_chunk_log2(void) { return CHUNK_LOG2; }
 
 static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out, uint32_t *raw_out,
                        uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys, int jump_levels,
-                       const uint32_t *radix_polys, int radix_levels, void *workspace, size_t workspace_bytes,
-                       ps_stream_t stream);
+                       const uint32_t *radix_polys, int radix_levels, const uint32_t *window_polys, int n_window,
+                       void *workspace, size_t workspace_bytes, ps_stream_t stream);
 
 extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,
                                         uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys,
-                                        int jump_levels, const uint32_t *radix_polys, int radix_levels, void *workspace,
+                                        int jump_levels, const uint32_t *radix_polys, int radix_levels,
+                                        const uint32_t *window_polys, int n_window, void *workspace,
                                         size_t workspace_bytes, ps_stream_t stream) {
     return mt_generate(state_in, pos_in, skip, n, out, nullptr, state_out, pos_out, jump_polys, jump_levels, radix_polys,
-                       radix_levels, workspace, workspace_bytes, stream);
+                       radix_levels, window_polys, n_window, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ps_mt19937_raw_stream(const uint32_t *state_in, int pos_in, int64_t n, uint32_t *raw, uint32_t *state_out,
                                      int32_t *pos_out, const uint32_t *jump_polys, int jump_levels,
-                                     const uint32_t *radix_polys, int radix_levels, void *workspace, size_t workspace_bytes,
-                                     ps_stream_t stream) {
+                                     const uint32_t *radix_polys, int radix_levels, const uint32_t *window_polys,
+                                     int n_window, void *workspace, size_t workspace_bytes, ps_stream_t stream) {
     if (!raw || !jump_polys || !workspace || n < (1 << 17)) return PS_EINVAL;
     return mt_generate(state_in, pos_in, 0, n, nullptr, raw, state_out, pos_out, jump_polys, jump_levels, radix_polys,
-                       radix_levels, workspace, workspace_bytes, stream);
+                       radix_levels, window_polys, n_window, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n) {
     if (n < 0 || skip < 0) return 0;
     const Plan p = make_plan(MT_N, skip, n);            // pos only shifts the plan by < 624 words
-    const int64_t K = p.c1 - p.c0 + 2;
+    const int64_t K = p.c1 - p.c0 + 3;
     const size_t states = align256((size_t)(K + 4) * JP * MT_N * 4);
     const size_t seqs = align256((size_t)(K / 2 + 2) * SEQ_PAD * 4);
     return states + seqs + align256((size_t)(p.w_hi - p.w_lo + 2 * MT_N + CHUNK) * 4) + 4096;
@@ -522,8 +654,8 @@ extern "C" size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n) {
 
 static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out, uint32_t *raw_out,
                        uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys,
-                       int jump_levels, const uint32_t *radix_polys, int radix_levels, void *workspace,
-                       size_t workspace_bytes, ps_stream_t stream) {
+                       int jump_levels, const uint32_t *radix_polys, int radix_levels, const uint32_t *window_polys,
+                       int n_window, void *workspace, size_t workspace_bytes, ps_stream_t stream) {
     if (!state_in || !state_out || !pos_out || n < 0 || skip < 0 || pos_in < 0 || pos_in > MT_N) return PS_EINVAL;
     if (n > 0 && !out && !raw_out) return PS_EINVAL;
     hipStream_t st = ps_stream(stream);
@@ -563,26 +695,78 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
         if (p.w_lo != 0) return PS_EUNSUPPORTED;         // (skip = 0: word 2i is the first word of uniform i)
         raw = raw_out;
     }
-    // 1. W1 (part 0 of tmpA, the other parts zero) and word 0
-    if (hipMemsetAsync(tmpA, 0, WSZ * 4, st) != hipSuccess) return PS_ELAUNCH;
-    hipLaunchKernelGGL(mt_prepare_kernel, dim3(1), dim3(256), 0, st, state_in, pos_in, tmpA, word0);
-    PS_CHECK_LAUNCH();
-    // 2. base jump to chunk c0: offset c0 * CHUNK words = set bits of c0 at levels CHUNK_LOG2 + b
-    uint32_t *cur = tmpA, *nxt = tmpB;
-    for (int b = 0; (p.c0 >> b) != 0; ++b) {
-        if (!((p.c0 >> b) & 1)) continue;
-        hipLaunchKernelGGL(mt_expand_kernel, dim3(1), dim3(256), 0, st, cur, JP, (int64_t)WSZ, seqs);
-        PS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(mt_combine_kernel, dim3(JP), dim3(192), 0, st, seqs, jump_polys + (size_t)(CHUNK_LOG2 + b) * MT_N, nxt);
-        PS_CHECK_LAUNCH();
-        uint32_t *t = cur; cur = nxt; nxt = t;
-    }
-    if (hipMemcpyAsync(states, cur, WSZ * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
-    // 3. chunk windows: radix-32 rounds (window j * have + r = jump_{j * have chunks}(window r), j = 1..31) when the
-    //    multiplier polynomials are given -- two rounds instead of eight serial expansions for 180 chunks -- else doubling
+    // One-round windows (window_polys: row j - 1 = t^(j * CHUNK) mod phi, at least K - 1 rows): every chunk window is ONE jump
+    // from the first one, all K - 1 products in a single round on the matrix cores -- launches: begin (window 0, its expansion,
+    // A operands), planes, products, reduce, finish, chunks, instead of the 16 of the two-round scheme (r03: 184 -> ... us for
+    // the 361 windows of a two-layer walk pass; the second round's source windows had to wait for a whole first round)
     bool plain_states = false;
     uint32_t *plainS = nullptr;
-    if (radix_polys && radix_levels >= 2 && K > 32 && K <= 1024) {
+    const int ngroups = (int)((K - 1 + 31) / 32);
+    bool one_round = window_polys != nullptr && K > 32 && K - 1 <= n_window;
+    uint32_t *seqM = nullptr, *planes1 = nullptr;
+    uint4 *polyAw = nullptr;
+    uint16_t *PLw = reinterpret_cast<uint16_t *>(states + WSZ);
+    const int parts_w = ngroups * 32 * 7 >= 1024 ? 7 : 21;
+    if (one_round) {
+        char *q = reinterpret_cast<char *>(seqs);
+        const char *q_end = q + align256((size_t)(K / 2 + 2) * SEQ_PAD * 4);
+        seqM = reinterpret_cast<uint32_t *>(q);       q += align256((size_t)SEQ_PAD * 4);
+        planes1 = reinterpret_cast<uint32_t *>(q);    q += align256((size_t)32 * PLW * 4);
+        polyAw = reinterpret_cast<uint4 *>(q);        q += align256((size_t)ngroups * KS_TOTAL * 64 * 16);
+        plainS = reinterpret_cast<uint32_t *>(q);     q += align256((size_t)K * MT_N * 4);
+        one_round = q <= q_end && (size_t)parts_w * ngroups * 32 * JT * 32 <= (size_t)(K - 1) * WSZ;
+    }
+    const unsigned pack_blocks = (unsigned)(((int64_t)ngroups * KS_TOTAL * 64 + 255) / 256);
+    if (one_round && p.c0 == 0) {
+        hipLaunchKernelGGL(mt_begin_kernel, dim3(1 + pack_blocks), dim3(256), 0, st, state_in, pos_in, plainS, word0, seqM, window_polys,
+                           (int)(K - 1), ngroups, polyAw);
+        PS_CHECK_LAUNCH();
+    } else {
+        // 1. W1 (part 0 of tmpA, the other parts zero) and word 0
+        if (hipMemsetAsync(tmpA, 0, WSZ * 4, st) != hipSuccess) return PS_ELAUNCH;
+        hipLaunchKernelGGL(mt_prepare_kernel, dim3(1), dim3(256), 0, st, state_in, pos_in, tmpA, word0);
+        PS_CHECK_LAUNCH();
+        // 2. base jump to chunk c0: offset c0 * CHUNK words = set bits of c0 at levels CHUNK_LOG2 + b
+        uint32_t *cur = tmpA, *nxt = tmpB;
+        for (int b = 0; (p.c0 >> b) != 0; ++b) {
+            if (!((p.c0 >> b) & 1)) continue;
+            hipLaunchKernelGGL(mt_expand_kernel, dim3(1), dim3(256), 0, st, cur, JP, (int64_t)WSZ, seqs);
+            PS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(mt_combine_kernel, dim3(JP), dim3(192), 0, st, seqs, jump_polys + (size_t)(CHUNK_LOG2 + b) * MT_N, nxt);
+            PS_CHECK_LAUNCH();
+            uint32_t *t = cur; cur = nxt; nxt = t;
+        }
+        if (hipMemcpyAsync(states, cur, WSZ * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
+        if (one_round) {                                // after a skipped prefix: window c0 is in `states`, JP parts
+            hipLaunchKernelGGL(mt_begin_kernel, dim3(1 + pack_blocks), dim3(256), 0, st, (const uint32_t *)nullptr, 0, plainS, word0, seqM,
+                               window_polys, (int)(K - 1), ngroups, polyAw);
+            PS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(mt_fold_kernel, dim3(3), dim3(256), 0, st, states, plainS);
+            PS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(mt_expand_kernel, dim3(1), dim3(256), 0, st, plainS, 1, (int64_t)0, seqM);
+            PS_CHECK_LAUNCH();
+        }
+    }
+    if (one_round) {
+        hipLaunchKernelGGL(mt_planes_kernel, dim3((SEQ_PAD / 64 + 4) / 4, 1), dim3(256), 0, st, seqM, planes1);
+        PS_CHECK_LAUNCH();
+        const int steps = KS_TOTAL / parts_w;
+        const size_t lds = (size_t)MF_PLANES * 8 * (4 * (2 * steps + JT + 1) + 8) * 4;
+        hipLaunchKernelGGL(mt_jump_mfma_kernel, dim3((unsigned)(ngroups * (32 / MF_PLANES) * parts_w)), dim3(256), lds, st, planes1, polyAw, PLw, ngroups,
+                           parts_w, steps, ngroups);
+        PS_CHECK_LAUNCH();
+        const int64_t slice = (int64_t)ngroups * 32 * JT * 32;
+        hipLaunchKernelGGL(mt_jump_reduce_kernel, dim3((unsigned)ps_cdiv(slice, 256)), dim3(256), 0, st, reinterpret_cast<uint32_t *>(PLw),
+                           slice, parts_w);
+        PS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(mt_jump_finish_kernel, dim3((unsigned)ps_cdiv((int64_t)ngroups * 32 * MT_N, 256)), dim3(256), 0, st, PLw, ngroups,
+                           32, (int64_t)32, (int64_t)1, K, plainS);
+        PS_CHECK_LAUNCH();
+        plain_states = true;
+    }
+    // 3. chunk windows: radix-32 rounds (window j * have + r = jump_{j * have chunks}(window r), j = 1..31) when the
+    //    multiplier polynomials are given -- two rounds instead of eight serial expansions for 180 chunks -- else doubling
+    if (!plain_states && radix_polys && radix_levels >= 2 && K > 32 && K <= 1024) {
         // two radix-32 rounds on the matrix cores, big strides first: round A makes the windows 32 j (j = 1..JA) from window 0
         // (polynomials of level 1), round B the windows 32 a + j (j = 1..31) from the windows 32 a, a = 0..JA (level 0): every
         // product of round B shares its source with 30 others, which is what fills the 32 rows of the MFMA
@@ -613,9 +797,9 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
                 hipLaunchKernelGGL(mt_planes_kernel, dim3((SEQ_PAD / 64 + 4) / 4, (unsigned)nsrc), dim3(256), 0, st, seqM, planes);
                 PS_CHECK_LAUNCH();
                 const int steps = KS_TOTAL / parts;
-                const size_t lds = (size_t)8 * (4 * (2 * steps + JT + 1) + 8) * 4;
-                hipLaunchKernelGGL(mt_jump_mfma_kernel, dim3((unsigned)(nsrc * 32 * parts)), dim3(256), lds, st, planes, polyA, PLp, nsrc,
-                                   parts, steps);
+                const size_t lds = (size_t)MF_PLANES * 8 * (4 * (2 * steps + JT + 1) + 8) * 4;
+                hipLaunchKernelGGL(mt_jump_mfma_kernel, dim3((unsigned)(nsrc * (32 / MF_PLANES) * parts)), dim3(256), lds, st, planes, polyA, PLp, nsrc,
+                                   parts, steps, 1);
                 PS_CHECK_LAUNCH();
                 const int64_t total = (int64_t)nsrc * rows * MT_N;
                 const int64_t slice = (int64_t)nsrc * 32 * JT * 32;                     // dwords (two 16-bit entries each)
@@ -659,8 +843,9 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
         }
     }
     // 4. chunks -> raw words; word 0 separately
-    if (plain_states) hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)K), dim3(256), 0, st, plainS, 1, p.c0, p.w_lo, p.w_hi, raw);
-    else hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)K), dim3(256), 0, st, states, JP, p.c0, p.w_lo, p.w_hi, raw);
+    const int64_t key_fold = p.key_w >= 1 ? p.key_w : -(int64_t)4 * MT_N;         // no stream word lies in the folded range then
+    hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)K, 2), dim3(256), 0, st, plain_states ? plainS : states, plain_states ? 1 : JP, p.c0,
+                       p.w_lo, p.w_hi, raw, key_fold, state_out, p.pos_out, pos_out);
     PS_CHECK_LAUNCH();
     if (p.w_lo == 0)
         if (hipMemcpyAsync(raw, word0, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
@@ -672,7 +857,9 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
         PS_CHECK_LAUNCH();
     }
     // 6. the state numpy would be left in
-    if (p.key_w >= 0) {
+    if (p.key_w >= 1) {
+        // stored by the chunk generators
+    } else if (p.key_w == 0) {
         hipLaunchKernelGGL(mt_final_state_kernel, dim3(1), dim3(640), 0, st, raw, p.w_lo, p.key_w, p.pos_out, state_out, pos_out);
         PS_CHECK_LAUNCH();
     } else {

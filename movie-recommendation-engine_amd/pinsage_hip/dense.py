@@ -300,6 +300,19 @@ def _radix_polys(dev):
     return _radix_polys_dev[key]
 
 
+_window_polys_dev = {}
+
+
+def _window_polys(dev):
+    key = str(dev)
+    if key not in _window_polys_dev:
+        from . import mtjump
+        import numpy as np
+        cl2 = int(nv.lib().ps_mt19937_chunk_log2())
+        _window_polys_dev[key] = torch.from_numpy(mtjump.window_polynomials(cl2).view(np.int32)).to(dev).contiguous()
+    return _window_polys_dev[key]
+
+
 _pending_state = []
 
 
@@ -314,7 +327,7 @@ def finish_rng_state():
         np.random.set_state((name, host_state.numpy().view(np.uint32).copy(), int(host_pos.item()), has_gauss, cached))
 
 
-def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=True, raw=False):
+def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=True, raw=False, one_round=True):
     """n doubles of the process-global numpy legacy stream generated ON THE DEVICE (after skipping `skip`
     doubles); with advance=True the global np.random state is advanced exactly as
     `np.random.random_sample(skip + n)` would (reference utils/random_walk.py:79 draws these one at a time).
@@ -337,6 +350,7 @@ def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=
            torch.empty(int(n), dtype=torch.float64, device=dev))
     polys = _jump_polys(dev) if parallel else None
     rpolys = _radix_polys(dev) if (parallel and radix) else None      # radix=False: windows by doubling
+    wpolys = _window_polys(dev) if (parallel and radix and one_round) else None    # one_round=False: two radix-32 rounds
     L = nv.lib()
     wsb = int(L.ps_mt19937_workspace_bytes(nv.i64(int(skip)), nv.i64(int(n)))) if parallel else 0
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if parallel else None
@@ -344,12 +358,14 @@ def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=
         if raw:
             nv.call("ps_mt19937_raw_stream", nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(n)), nv.ptr(out), nv.ptr(st_out),
                     nv.ptr(pos_out), nv.ptr(polys), nv.i32(int(polys.size(0))), nv.ptr(rpolys),
-                    nv.i32(int(rpolys.size(0)) if rpolys is not None else 0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
+                    nv.i32(int(rpolys.size(0)) if rpolys is not None else 0), nv.ptr(wpolys),
+                    nv.i32(int(wpolys.size(0)) if wpolys is not None else 0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
         else:
           nv.call("ps_mt19937_random_sample", nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(skip)), nv.i64(int(n)),
                 nv.ptr(out), nv.ptr(st_out), nv.ptr(pos_out), nv.ptr(polys),
                 nv.i32(int(polys.size(0)) if polys is not None else 0), nv.ptr(rpolys),
-                nv.i32(int(rpolys.size(0)) if rpolys is not None else 0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
+                nv.i32(int(rpolys.size(0)) if rpolys is not None else 0), nv.ptr(wpolys),
+                nv.i32(int(wpolys.size(0)) if wpolys is not None else 0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
     if advance == "defer":
         finish_rng_state()                                           # at most one hand-back in flight
         host_state = torch.empty(624, dtype=torch.int32).pin_memory()

@@ -246,6 +246,24 @@ def test_device_mt19937_matches_numpy():
     a = dense.mt19937_random_sample(200000, "cuda", advance=False, parallel=False)
     b = dense.mt19937_random_sample(200000, "cuda", advance=False, parallel=True)
     assert torch.equal(a, b)
+    # one-round windows (the default for 33..512 chunks) and the two radix-32 rounds agree: doubles, raw words, numpy state
+    for seed, burn, n in ((31, 0, 11_809_400), (37, 3, 2_200_000), (41, 1, 33_000_000)):
+        outs = []
+        for one_round in (True, False):
+            np.random.seed(seed)
+            np.random.random_sample(burn)
+            d = dense.mt19937_random_sample(n, "cuda", one_round=one_round)
+            t1 = np.random.random_sample()
+            np.random.seed(seed)
+            np.random.random_sample(burn)
+            r = dense.mt19937_random_sample(n, "cuda", raw=True, one_round=one_round)
+            t2 = np.random.random_sample()
+            outs.append((d, r[:2 * n], t1, t2))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert outs[0][2] == outs[1][2] == outs[0][3] == outs[1][3]
+        rs = np.random.RandomState(seed)
+        rs.random_sample(burn)
+        assert np.array_equal(outs[0][0].cpu().numpy(), rs.random_sample(n)) and rs.random_sample() == outs[0][2]
     # chunk windows by doubling (no radix-16 table) and by radix-16 rounds agree, incl. > 16 and > 256 chunks
     for n in (3_000_000, 20_000_000):
         np.random.seed(21)

@@ -59,3 +59,24 @@ def test_radix_polynomials_agree_with_the_binary_table():
         a, b = (j & -j), j - (j & -j)                              # split j into two smaller multipliers
         prod = mtjump._reduce(mtjump._mul(as_int(R[i, a - 1]), as_int(R[i, b - 1])), phi)
         assert prod == as_int(R[i, j - 1])
+
+
+def test_window_polynomials_are_the_single_jumps():
+    """row j-1 = t^(j * 2^c): rows 1..31 and 32 j are the radix tables' entries, every row is the product of two smaller
+    ones, and a jump applied through the recurrence lands on the window j * 2^c words later (small c: the check walks
+    the sequence)."""
+    from pinsage_hip import mtjump
+    c = 17
+    W, R = mtjump.window_polynomials(c), mtjump.radix_polynomials(c)
+    assert W.shape == (mtjump.WINDOW_POLYS, 624) and W.dtype == np.uint32
+    assert all(np.array_equal(W[j - 1], R[0, j - 1]) for j in range(1, 32))
+    assert all(np.array_equal(W[32 * j - 1], R[1, j - 1]) for j in range(1, 16))
+    phi = mtjump.characteristic_polynomial()
+    as_int = lambda row: int.from_bytes(row.astype("<u4").tobytes(), "little")
+    for j in (33, 100, 361, 511):
+        a = j // 2
+        assert mtjump._reduce(mtjump._mul(as_int(W[a - 1]), as_int(W[j - a - 1])), phi) == as_int(W[j - 1])
+    # the sparse reduction agrees with the bit-serial one
+    taps = [i for i in range(mtjump.DEG) if (phi >> i) & 1]
+    p = mtjump._mul(as_int(W[76]), as_int(W[12]))
+    assert mtjump._reduce_sparse(p, phi, taps) == mtjump._reduce(p, phi)

@@ -11,5 +11,12 @@ last={}
 for r in rows[-16:]:
     last.setdefault(r["Kernel_Name"].split("::")[-1].split("(")[0], []).append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
 print("variant $v:", {k: [round(x,1) for x in v] for k,v in last.items()})
+t0=min(int(r["Start_Timestamp"]) for r in rows[-16:]); t1=max(int(r["End_Timestamp"]) for r in rows[-16:])
+print("  last call: span %.1f us, kernel time %.1f us, gaps %.1f us" % ((t1-t0)/1e3, sum(sum(v) for v in last.values()), (t1-t0)/1e3-sum(sum(v) for v in last.values())))
+prev=None
+for r in sorted(rows[-16:], key=lambda r:int(r["Start_Timestamp"])):
+    s0,e0=int(r["Start_Timestamp"]),int(r["End_Timestamp"])
+    print("   %-28s start +%7.1f us  dur %6.1f us  gap before %5.1f us" % (r["Kernel_Name"].split("::")[-1].split("(")[0][:28], (s0-t0)/1e3, (e0-s0)/1e3, 0 if prev is None else (s0-prev)/1e3))
+    prev=e0
 PY
 done

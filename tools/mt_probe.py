@@ -17,3 +17,11 @@ for _ in range(5):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); dense.mt19937_random_sample(n, dev); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
 print(f"n={n}: min {min(ts):.3f} ms -> {n / min(ts) / 1e6:.2f} G doubles/s")
+# the walk sampler's form: raw state words, the numpy state handed back asynchronously (what a bench step pays)
+ts = []
+for _ in range(8):
+    np.random.seed(0)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); dense.mt19937_random_sample(n, dev, raw=True, advance="defer"); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+dense.finish_rng_state()
+print(f"raw stream n={n}: min {min(ts):.3f} ms, median {sorted(ts)[len(ts) // 2]:.3f} ms (event pair around host enqueue + device work)")

@@ -33,6 +33,12 @@ for k in names:
 open(out_txt, "w").write("\n".join(lines) + "\n")
 
 
+def _gemm_epi(k):
+    import re
+    m = re.match(r"gemm_f32_p?kernel<\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*(\d+)", k)
+    return int(m.group(1)) if m else -1
+
+
 def per_launch(pred):
     """kernels that one call launches together (scan + merge): per-launch means add up"""
     tot = 0.0
@@ -55,14 +61,13 @@ out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, ben
        "ps_walk_sample_layers": per_launch(lambda k: k.startswith("walk_sample_kernel")),
        "ps_hamming_topk_mfma": per_launch(lambda k: k.startswith("hamming_mfma_kernel") or k.startswith("bound_select_kernel")
                                           or k.startswith("slice_merge_kernel")),
-       "ps_mt19937_raw_stream": per_launch(lambda k: k.startswith("mt_chunk_kernel") or k.startswith("mt_final_state") or k.startswith("mt_prepare")) +
-                                2 * per_launch(lambda k: k.startswith("mt_combine_radix") or k.startswith("mt_expand")),
-       "ps_mt19937_random_sample": per_launch(lambda k: k.startswith("mt_chunk_kernel") or k.startswith("mt_raw_to_double")
-                                              or k.startswith("mt_final_state") or k.startswith("mt_prepare")) +
-                                   3 * per_launch(lambda k: k.startswith("mt_combine_radix") or k.startswith("mt_expand")),
+       # every mt_* kernel of the one-round generator runs once per call (begin, planes, jump products, reduce, finish, chunks)
+       "ps_mt19937_raw_stream": per_launch(lambda k: k.startswith("mt_") and not k.startswith("mt_raw_to_double")),
+       "ps_mt19937_random_sample": per_launch(lambda k: k.startswith("mt_")),
        "ps_importance_pool": per_launch(lambda k: k.startswith("importance_pool_kernel")),
-       "ps_linear": per_call(lambda k: k.startswith("gemm_f32_kernel") and ", 0, " in k),
-       "ps_lsh_encode": per_call(lambda k: k.startswith("gemm_f32_kernel") and ", 1, " in k),
+       # template arguments <WM, WN, TM, TN, BK, EPI[, FAST]>: EPI 0 = ps_linear, 1 = ps_lsh_encode (one-tile and persistent kernels)
+       "ps_linear": per_call(lambda k: _gemm_epi(k) == 0),
+       "ps_lsh_encode": per_call(lambda k: _gemm_epi(k) == 1),
        "ps_hamming_topk": per_launch(lambda k: k.startswith("hamming_scan_kernel") or k.startswith("topk_merge_kernel"))}
 json.dump(out, open(out_json, "w"), indent=1)
 print(open(out_txt).read())
