@@ -29,6 +29,21 @@ constexpr int DEG = 19937;
 constexpr int CHUNK_LOG2 = 17;                          // 2^16: more jumps than chunk time saved (1.09 vs 0.94 ms for 11.8 M doubles)
 constexpr int64_t CHUNK = (int64_t)1 << CHUNK_LOG2;     // words per chunk
 
+// The chunk windows a request needs, as up to four runs of window indices (window w starts at stream word 1 + w * CHUNK): slot 0
+// is always window 0 (free: it comes from the state itself), slot 1 + q is window win_of(q).  A whole-stream request is one run
+// 1 .. K - 1; a rank of a sharded job asks only for the words of ITS start nodes (ps_mt19937_raw_stream `ranges`).
+struct WinSet { int n; long long first[4]; long long cum[5]; };
+struct Wanted { int n; long long lo[4], hi[4]; };             // wanted stream words: union of [lo, hi)
+// (literal indices only: a run-time index into a by-value kernel argument sends the whole struct to scratch memory -- the chunk
+// kernel took 149 us instead of 40 with loops over wt.n)
+__host__ __device__ __forceinline__ long long win_of(const WinSet &ws, long long q) {
+    long long w = ws.first[0] + q;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < ws.n && q >= ws.cum[i]) w = ws.first[i] + (q - ws.cum[i]);
+    return w;
+}
+
 __device__ __forceinline__ uint32_t twist(uint32_t u, uint32_t v) {
     const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
     return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
@@ -314,10 +329,11 @@ __global__ __launch_bounds__(256) void mt_pack_polys_kernel(const uint32_t *__re
 // First launch of the one-round scheme.  Workgroup 0 (when `state_in` is given): the window W1 at stream word 1 and word 0 from
 // numpy's state (= mt_prepare_kernel), W1 to plain0, and its expansion to 34 blocks (= mt_expand_kernel) -- a serial chain of
 // 36 block updates; the other workgroups meanwhile expand `ngroups` 32-row groups of the window-polynomial table into MFMA A
-// operands (= mt_pack_polys_kernel per group; rows >= nrows: zero).
+// operands (= mt_pack_polys_kernel per group; product q applies table row win_of(q) - 1; q >= nrows: zero).
 __global__ __launch_bounds__(256) void mt_begin_kernel(const uint32_t *__restrict__ state_in, int pos_in, uint32_t *__restrict__ plain0,
                                                        uint32_t *__restrict__ word0, uint32_t *__restrict__ seq,
-                                                       const uint32_t *__restrict__ polys, int nrows, int ngroups, uint4 *__restrict__ polyA) {
+                                                       const uint32_t *__restrict__ polys, int nrows, int ngroups, uint4 *__restrict__ polyA,
+                                                       WinSet ws) {
     const int t = threadIdx.x;
     if (blockIdx.x == 0) {
         if (state_in == nullptr) return;
@@ -346,8 +362,8 @@ __global__ __launch_bounds__(256) void mt_begin_kernel(const uint32_t *__restric
     const int64_t idx = (int64_t)(blockIdx.x - 1) * 256 + t;
     if (idx >= (int64_t)ngroups * KS_TOTAL * 64) return;
     const int g = (int)(idx / (KS_TOTAL * 64)), rem = (int)(idx % (KS_TOTAL * 64));
-    const int ks = rem >> 6, lane = rem & 63, row = 32 * g + (lane & 31), w = 2 * ks + (lane >> 5);
-    const uint32_t word = (row < nrows && w < MT_N) ? polys[(size_t)row * MT_N + w] : 0u;
+    const int ks = rem >> 6, lane = rem & 63, q = 32 * g + (lane & 31), w = 2 * ks + (lane >> 5);
+    const uint32_t word = (q < nrows && w < MT_N) ? polys[(size_t)(win_of(ws, q) - 1) * MT_N + w] : 0u;    // product q: window win_of(q) = table row - 1
     polyA[idx] = make_uint4(bits_to_fp4(word & 255u), bits_to_fp4((word >> 8) & 255u), bits_to_fp4((word >> 16) & 255u),
                             bits_to_fp4(word >> 24));
 }
@@ -515,23 +531,35 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const uint32_t *parts, uin
 constexpr int64_t HALF = CHUNK / 2;
 // The 624 words from key_w on are also the state numpy is left in: stored to state_out by whoever produces them (key_w < 1:
 // none here, mt_final_state_kernel copies them).
-__global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, int nparts, int64_t c0, int64_t w_lo,
-                                                       int64_t w_hi, uint32_t *raw, int64_t key_w, uint32_t *state_out, int pos,
-                                                       int32_t *pos_out) {
+// Slot blockIdx.x holds window (slot == 0 ? 0 : win_of(slot - 1)) + c0; only words of `wt` are stored.
+__global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, int nparts, int64_t c0, WinSet ws, Wanted wt, int64_t w_lo,
+                                                       uint32_t *raw, int64_t key_w, uint32_t *state_out, int pos, int32_t *pos_out) {
     __shared__ uint32_t mt[2][MT_N];
     const int t = threadIdx.x;
     const bool back = blockIdx.y != 0;
     if (blockIdx.x == 0 && !back && t == 0 && key_w >= 1) pos_out[0] = pos;
-    const int64_t wbase = 1 + (c0 + blockIdx.x) * CHUNK;
-    // wanted words of this workgroup: [lo, hi)
-    int64_t lo = back ? wbase - HALF : wbase, hi = back ? wbase : wbase + HALF;
-    if (lo < w_lo) lo = w_lo;
-    if (lo < 1) lo = 1;
-    if (hi > w_hi) hi = w_hi;
+    const int64_t wbase = 1 + (c0 + (blockIdx.x == 0 ? 0 : win_of(ws, blockIdx.x - 1))) * CHUNK;
+    // wanted words of this workgroup: the part of wt inside its half chunk [h_lo, h_hi); [lo, hi) = the hull of that part
+    int64_t h_lo = back ? wbase - HALF : wbase, h_hi = back ? wbase : wbase + HALF;
+    if (h_lo < 1) h_lo = 1;
+    int64_t lo = h_hi, hi = h_lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < wt.n) {
+            const int64_t a = wt.lo[i] > h_lo ? wt.lo[i] : h_lo, b = wt.hi[i] < h_hi ? wt.hi[i] : h_hi;
+            if (a < b) { lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+        }
+    }
     if (lo >= hi) return;                                      // block-uniform
+    auto wanted = [&](int64_t w) {
+        bool in = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) in = in || (i < wt.n && w >= wt.lo[i] && w < wt.hi[i]);
+        return in && w >= h_lo && w < h_hi;
+    };
     auto put = [&](int64_t w0, int i, uint32_t v) {            // word i of the block that starts at stream word w0
         const int64_t w = w0 + i;
-        if (w >= lo && w < hi) {
+        if (wanted(w)) {
             raw[w - w_lo] = v;
             if (w >= key_w && w < key_w + MT_N) state_out[w - key_w] = v;
         }
@@ -543,13 +571,24 @@ __global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, i
     }
     __syncthreads();
     auto step = [&](const uint32_t *o, uint32_t *n, int64_t w0) {
-        if (w0 >= lo && w0 + MT_N <= hi && (w0 + MT_N <= key_w || w0 >= key_w + MT_N)) {   // whole block wanted, no state word in it (scalar test): no per-word tests
+        bool whole = false;                                    // whole block inside ONE wanted run and this half chunk, no state word in it (scalar test)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) whole = whole || (i < wt.n && w0 >= wt.lo[i] && w0 + MT_N <= wt.hi[i]);
+        if (whole && w0 >= h_lo && w0 + MT_N <= h_hi && (w0 + MT_N <= key_w || w0 >= key_w + MT_N)) {   // no per-word tests
             uint32_t *dst = raw + (w0 - w_lo);
             if (back) prev_block_emit(o, n, t, [&](int i, uint32_t v) { if (!(PS_MT_DEBUG & 16) || v == 0x12345u) dst[i] = v; });
             else next_block_emit(o, n, t, [&](int i, uint32_t v) { if (!(PS_MT_DEBUG & 16) || v == 0x12345u) dst[i] = v; });
         } else {
-            if (back) prev_block_emit(o, n, t, [&](int i, uint32_t v) { put(w0, i, v); });
-            else next_block_emit(o, n, t, [&](int i, uint32_t v) { put(w0, i, v); });
+            bool any = false;                                  // a block on the way to the wanted words stores nothing (scalar test too:
+#pragma unroll                                                 // the per-word tests made such a chain 2.5 x slower than a stored one)
+            for (int i = 0; i < 4; ++i) any = any || (i < wt.n && w0 < wt.hi[i] && w0 + MT_N > wt.lo[i]);
+            if (!any) {
+                if (back) prev_block_emit(o, n, t, [&](int, uint32_t) {});
+                else next_block_emit(o, n, t, [&](int, uint32_t) {});
+            } else {
+                if (back) prev_block_emit(o, n, t, [&](int i, uint32_t v) { put(w0, i, v); });
+                else next_block_emit(o, n, t, [&](int i, uint32_t v) { put(w0, i, v); });
+            }
         }
     };
     if (!back) {
@@ -623,7 +662,7 @@ extern "C" int ps_mt19937_chunk_log2(void) { return CHUNK_LOG2; }
 static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out, uint32_t *raw_out,
                        uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys, int jump_levels,
                        const uint32_t *radix_polys, int radix_levels, const uint32_t *window_polys, int n_window,
-                       void *workspace, size_t workspace_bytes, ps_stream_t stream);
+                       const int64_t *ranges_host, int n_ranges, void *workspace, size_t workspace_bytes, ps_stream_t stream);
 
 extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out,
                                         uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys,
@@ -631,22 +670,24 @@ extern "C" int ps_mt19937_random_sample(const uint32_t *state_in, int pos_in, in
                                         const uint32_t *window_polys, int n_window, void *workspace,
                                         size_t workspace_bytes, ps_stream_t stream) {
     return mt_generate(state_in, pos_in, skip, n, out, nullptr, state_out, pos_out, jump_polys, jump_levels, radix_polys,
-                       radix_levels, window_polys, n_window, workspace, workspace_bytes, stream);
+                       radix_levels, window_polys, n_window, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ps_mt19937_raw_stream(const uint32_t *state_in, int pos_in, int64_t n, uint32_t *raw, uint32_t *state_out,
                                      int32_t *pos_out, const uint32_t *jump_polys, int jump_levels,
                                      const uint32_t *radix_polys, int radix_levels, const uint32_t *window_polys,
-                                     int n_window, void *workspace, size_t workspace_bytes, ps_stream_t stream) {
-    if (!raw || !jump_polys || !workspace || n < (1 << 17)) return PS_EINVAL;
+                                     int n_window, const int64_t *ranges_host, int n_ranges, void *workspace,
+                                     size_t workspace_bytes, ps_stream_t stream) {
+    if (!raw || !jump_polys || !workspace || n < (1 << 17) || n_ranges < 0 || (n_ranges > 0 && !ranges_host)) return PS_EINVAL;
     return mt_generate(state_in, pos_in, 0, n, nullptr, raw, state_out, pos_out, jump_polys, jump_levels, radix_polys,
-                       radix_levels, window_polys, n_window, workspace, workspace_bytes, stream);
+                       radix_levels, window_polys, n_window, ranges_host, n_ranges, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n) {
     if (n < 0 || skip < 0) return 0;
     const Plan p = make_plan(MT_N, skip, n);            // pos only shifts the plan by < 624 words
-    const int64_t K = p.c1 - p.c0 + 3;
+    int64_t K = p.c1 - p.c0 + 3;
+    if (K < 128) K = 128;                               // room for the one-round products of short (ranged) requests
     const size_t states = align256((size_t)(K + 4) * JP * MT_N * 4);
     const size_t seqs = align256((size_t)(K / 2 + 2) * SEQ_PAD * 4);
     return states + seqs + align256((size_t)(p.w_hi - p.w_lo + 2 * MT_N + CHUNK) * 4) + 4096;
@@ -655,7 +696,8 @@ extern "C" size_t ps_mt19937_workspace_bytes(int64_t skip, int64_t n) {
 static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out, uint32_t *raw_out,
                        uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys,
                        int jump_levels, const uint32_t *radix_polys, int radix_levels, const uint32_t *window_polys,
-                       int n_window, void *workspace, size_t workspace_bytes, ps_stream_t stream) {
+                       int n_window, const int64_t *ranges_host, int n_ranges, void *workspace, size_t workspace_bytes,
+                       ps_stream_t stream) {
     if (!state_in || !state_out || !pos_out || n < 0 || skip < 0 || pos_in < 0 || pos_in > MT_N) return PS_EINVAL;
     if (n > 0 && !out && !raw_out) return PS_EINVAL;
     hipStream_t st = ps_stream(stream);
@@ -686,11 +728,12 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
     char *base = reinterpret_cast<char *>(align256(reinterpret_cast<size_t>(workspace)));
     const size_t WSZ = (size_t)JP * MT_N;                                    // words per stored window
     uint32_t *states = reinterpret_cast<uint32_t *>(base);                   // [K] chunk windows (JP parts each)
-    uint32_t *tmpA = states + (size_t)(K + 1) * WSZ;                         // ping-pong for the base jump
+    const int64_t Kc = K > 126 ? K : 126;                                    // the regions are carved for at least 126 windows (workspace_bytes: 128)
+    uint32_t *tmpA = states + (size_t)(Kc + 1) * WSZ;                        // ping-pong for the base jump
     uint32_t *tmpB = tmpA + WSZ;
     uint32_t *word0 = tmpB + WSZ;
-    uint32_t *seqs = reinterpret_cast<uint32_t *>(base + align256((size_t)(K + 4) * JP * MT_N * 4));
-    uint32_t *raw = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(seqs) + align256((size_t)(K / 2 + 2) * SEQ_PAD * 4));
+    uint32_t *seqs = reinterpret_cast<uint32_t *>(base + align256((size_t)(Kc + 4) * JP * MT_N * 4));
+    uint32_t *raw = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(seqs) + align256((size_t)(Kc / 2 + 2) * SEQ_PAD * 4));
     if (raw_out) {                                       // raw mode: the chunk generators write straight into the caller's buffer
         if (p.w_lo != 0) return PS_EUNSUPPORTED;         // (skip = 0: word 2i is the first word of uniform i)
         raw = raw_out;
@@ -699,27 +742,77 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
     // from the first one, all K - 1 products in a single round on the matrix cores -- launches: begin (window 0, its expansion,
     // A operands), planes, products, reduce, finish, chunks, instead of the 16 of the two-round scheme (r03: 184 -> ... us for
     // the 361 windows of a two-layer walk pass; the second round's source windows had to wait for a whole first round)
+    // Wanted words and window slots.  Default: everything in [w_lo, w_hi), windows 0 .. K - 1.  `ranges` (raw mode; a rank of a
+    // sharded job): only the words of the given runs of uniforms plus the 624 words of the state hand-back, and only the windows
+    // whose half chunks hold such words -- products, chunk chains and stores shrink with the share of the stream a rank consumes
+    // (words outside the runs are left unwritten).  Needs the one-round table; otherwise the whole stream is generated.
+    WinSet ws;
+    Wanted wt;
+    wt.n = 1; wt.lo[0] = p.w_lo; wt.hi[0] = p.w_hi;
+    ws.n = 1; ws.first[0] = 1; ws.cum[0] = 0; ws.cum[1] = K - 1;
+    int64_t Kw = K;                                      // window slots (slot 0 = window 0)
+    bool ranged = false;
+    if (ranges_host && n_ranges > 0 && n_ranges <= 3 && raw_out && skip == 0 && p.c0 == 0 && window_polys) {
+        long long a[4], b[4];
+        int m = 0;
+        for (int i = 0; i < n_ranges; ++i) {
+            const long long lo = ranges_host[2 * i] < 0 ? 0 : ranges_host[2 * i], hi = ranges_host[2 * i + 1] > n ? n : ranges_host[2 * i + 1];
+            if (lo < hi) { a[m] = 2 * lo; b[m] = 2 * hi; ++m; }
+        }
+        if (p.key_w >= 0) { a[m] = p.key_w; b[m] = p.key_w + MT_N; ++m; }
+        for (int i = 1; i < m; ++i)                      // sort by start, then merge runs that touch
+            for (int j = i; j > 0 && a[j] < a[j - 1]; --j) { long long t = a[j]; a[j] = a[j - 1]; a[j - 1] = t; t = b[j]; b[j] = b[j - 1]; b[j - 1] = t; }
+        int mm = 0;
+        for (int i = 0; i < m; ++i) {
+            if (mm > 0 && a[i] <= b[mm - 1]) { if (b[i] > b[mm - 1]) b[mm - 1] = b[i]; }
+            else { a[mm] = a[i]; b[mm] = b[i]; ++mm; }
+        }
+        long long f[4], l[4], maxwin = 0;
+        int nw = 0;
+        for (int i = 0; i < mm; ++i) {                   // window c serves the words [1 + c * CHUNK - HALF, 1 + c * CHUNK + HALF)
+            const long long a1 = a[i] < 1 ? 1 : a[i];
+            if (b[i] <= a1) continue;
+            long long clo = (a1 - 1 + HALF) / CHUNK;
+            const long long chi = (b[i] - 2 + HALF) / CHUNK;
+            if (clo == 0) clo = 1;                       // window 0 is slot 0
+            if (chi < clo) continue;
+            if (nw > 0 && clo <= l[nw - 1] + 1) { if (chi > l[nw - 1]) l[nw - 1] = chi; }
+            else { f[nw] = clo; l[nw] = chi; ++nw; }
+            maxwin = l[nw - 1];
+        }
+        if (mm > 0 && maxwin <= n_window) {
+            ranged = true;
+            wt.n = mm;
+            for (int i = 0; i < mm; ++i) { wt.lo[i] = a[i]; wt.hi[i] = b[i]; }
+            ws.n = nw > 0 ? nw : 1;
+            ws.cum[0] = 0; ws.cum[1] = 0; ws.first[0] = 1;
+            for (int i = 0; i < nw; ++i) { ws.first[i] = f[i]; ws.cum[i + 1] = ws.cum[i] + (l[i] - f[i] + 1); }
+            Kw = 1 + ws.cum[ws.n];
+        }
+    }
+    const int64_t nprod = Kw - 1;                        // windows that take a product
     bool plain_states = false;
     uint32_t *plainS = nullptr;
-    const int ngroups = (int)((K - 1 + 31) / 32);
-    bool one_round = window_polys != nullptr && K > 32 && K - 1 <= n_window;
+    const int ngroups = (int)((nprod + 31) / 32);
+    bool one_round = window_polys != nullptr && (ranged || (K > 32 && K - 1 <= n_window));
     uint32_t *seqM = nullptr, *planes1 = nullptr;
     uint4 *polyAw = nullptr;
     uint16_t *PLw = reinterpret_cast<uint16_t *>(states + WSZ);
-    const int parts_w = ngroups * 32 * 7 >= 1024 ? 7 : 21;
+    const int parts_w = ngroups * (32 / MF_PLANES) * 7 >= 512 ? 7 : 21;
     if (one_round) {
         char *q = reinterpret_cast<char *>(seqs);
-        const char *q_end = q + align256((size_t)(K / 2 + 2) * SEQ_PAD * 4);
+        const char *q_end = q + align256((size_t)(Kc / 2 + 2) * SEQ_PAD * 4);
         seqM = reinterpret_cast<uint32_t *>(q);       q += align256((size_t)SEQ_PAD * 4);
         planes1 = reinterpret_cast<uint32_t *>(q);    q += align256((size_t)32 * PLW * 4);
         polyAw = reinterpret_cast<uint4 *>(q);        q += align256((size_t)ngroups * KS_TOTAL * 64 * 16);
-        plainS = reinterpret_cast<uint32_t *>(q);     q += align256((size_t)K * MT_N * 4);
-        one_round = q <= q_end && (size_t)parts_w * ngroups * 32 * JT * 32 <= (size_t)(K - 1) * WSZ;
+        plainS = reinterpret_cast<uint32_t *>(q);     q += align256((size_t)Kw * MT_N * 4);
+        one_round = q <= q_end && (size_t)parts_w * ngroups * 32 * JT * 32 <= (size_t)(Kc - 1) * WSZ;
+        if (!one_round && ranged) return PS_EWORKSPACE;  // (cannot happen with ps_mt19937_workspace_bytes: 126 windows' room at least)
     }
     const unsigned pack_blocks = (unsigned)(((int64_t)ngroups * KS_TOTAL * 64 + 255) / 256);
     if (one_round && p.c0 == 0) {
         hipLaunchKernelGGL(mt_begin_kernel, dim3(1 + pack_blocks), dim3(256), 0, st, state_in, pos_in, plainS, word0, seqM, window_polys,
-                           (int)(K - 1), ngroups, polyAw);
+                           (int)nprod, ngroups, polyAw, ws);
         PS_CHECK_LAUNCH();
     } else {
         // 1. W1 (part 0 of tmpA, the other parts zero) and word 0
@@ -739,7 +832,7 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
         if (hipMemcpyAsync(states, cur, WSZ * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
         if (one_round) {                                // after a skipped prefix: window c0 is in `states`, JP parts
             hipLaunchKernelGGL(mt_begin_kernel, dim3(1 + pack_blocks), dim3(256), 0, st, (const uint32_t *)nullptr, 0, plainS, word0, seqM,
-                               window_polys, (int)(K - 1), ngroups, polyAw);
+                               window_polys, (int)nprod, ngroups, polyAw, ws);
             PS_CHECK_LAUNCH();
             hipLaunchKernelGGL(mt_fold_kernel, dim3(3), dim3(256), 0, st, states, plainS);
             PS_CHECK_LAUNCH();
@@ -747,7 +840,8 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
             PS_CHECK_LAUNCH();
         }
     }
-    if (one_round) {
+    if (one_round && nprod == 0) plain_states = true;    // a ranged request inside window 0's half chunk
+    if (one_round && nprod > 0) {
         hipLaunchKernelGGL(mt_planes_kernel, dim3((SEQ_PAD / 64 + 4) / 4, 1), dim3(256), 0, st, seqM, planes1);
         PS_CHECK_LAUNCH();
         const int steps = KS_TOTAL / parts_w;
@@ -760,7 +854,7 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
                            slice, parts_w);
         PS_CHECK_LAUNCH();
         hipLaunchKernelGGL(mt_jump_finish_kernel, dim3((unsigned)ps_cdiv((int64_t)ngroups * 32 * MT_N, 256)), dim3(256), 0, st, PLw, ngroups,
-                           32, (int64_t)32, (int64_t)1, K, plainS);
+                           32, (int64_t)32, (int64_t)1, Kw, plainS);
         PS_CHECK_LAUNCH();
         plain_states = true;
     }
@@ -844,8 +938,8 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
     }
     // 4. chunks -> raw words; word 0 separately
     const int64_t key_fold = p.key_w >= 1 ? p.key_w : -(int64_t)4 * MT_N;         // no stream word lies in the folded range then
-    hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)K, 2), dim3(256), 0, st, plain_states ? plainS : states, plain_states ? 1 : JP, p.c0,
-                       p.w_lo, p.w_hi, raw, key_fold, state_out, p.pos_out, pos_out);
+    hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)Kw, 2), dim3(256), 0, st, plain_states ? plainS : states, plain_states ? 1 : JP, p.c0,
+                       ws, wt, p.w_lo, raw, key_fold, state_out, p.pos_out, pos_out);
     PS_CHECK_LAUNCH();
     if (p.w_lo == 0)
         if (hipMemcpyAsync(raw, word0, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;

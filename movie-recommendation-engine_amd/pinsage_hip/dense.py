@@ -327,7 +327,7 @@ def finish_rng_state():
         np.random.set_state((name, host_state.numpy().view(np.uint32).copy(), int(host_pos.item()), has_gauss, cached))
 
 
-def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=True, raw=False, one_round=True):
+def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=True, raw=False, one_round=True, ranges=None):
     """n doubles of the process-global numpy legacy stream generated ON THE DEVICE (after skipping `skip`
     doubles); with advance=True the global np.random state is advanced exactly as
     `np.random.random_sample(skip + n)` would (reference utils/random_walk.py:79 draws these one at a time).
@@ -335,13 +335,16 @@ def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=
     keeps enqueueing the kernels that consume the uniforms instead of waiting for the generator (the caller must call
     finish_rng_state() before returning to code that may touch np.random).
     raw=True (skip = 0, n >= 2^17): returns the stream as untempered MT19937 words, int32[2n + 1248], for the walk kernels'
-    PS_RNG_STREAM_RAW mode (uniform i = words 2i, 2i + 1) instead of doubles."""
+    PS_RNG_STREAM_RAW mode (uniform i = words 2i, 2i + 1) instead of doubles.
+    ranges (raw only): up to three runs (lo, hi) of uniform indices the caller will read; only those words of the buffer are
+    generated (item shards: the stream positions of a rank's own start nodes), the np.random state still advances by n."""
     import numpy as np
     name, key, pos, has_gauss, cached = np.random.get_state()
     if name != "MT19937":
         raise RuntimeError("numpy global RNG is not MT19937")
     dev = torch.device(device)
-    st_in = torch.from_numpy(key.astype(np.uint32).view(np.int32)).to(dev)
+    # pinned staging + asynchronous copy: a pageable `.to(dev)` waits for the stream, i.e. for the whole previous step
+    st_in = torch.from_numpy(key.astype(np.uint32).view(np.int32)).pin_memory().to(dev, non_blocking=True)
     st_out = torch.empty(624, dtype=torch.int32, device=dev)
     pos_out = torch.empty(1, dtype=torch.int32, device=dev)
     if raw and (skip != 0 or not parallel or n < (1 << 17)):
@@ -354,12 +357,19 @@ def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=
     L = nv.lib()
     wsb = int(L.ps_mt19937_workspace_bytes(nv.i64(int(skip)), nv.i64(int(n)))) if parallel else 0
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if parallel else None
+    if ranges is not None and not raw:
+        raise ValueError("ranges: raw stream only")
+    rg = np.ascontiguousarray(np.asarray(ranges, dtype=np.int64).reshape(-1, 2)) if ranges is not None and len(ranges) else None
+    if rg is not None and rg.shape[0] > 3:
+        rg = None                                                    # more runs than the planner takes: generate everything
     with torch.cuda.device(dev):
         if raw:
             nv.call("ps_mt19937_raw_stream", nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(n)), nv.ptr(out), nv.ptr(st_out),
                     nv.ptr(pos_out), nv.ptr(polys), nv.i32(int(polys.size(0))), nv.ptr(rpolys),
                     nv.i32(int(rpolys.size(0)) if rpolys is not None else 0), nv.ptr(wpolys),
-                    nv.i32(int(wpolys.size(0)) if wpolys is not None else 0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
+                    nv.i32(int(wpolys.size(0)) if wpolys is not None else 0),
+                    rg.ctypes.data_as(nv.C.c_void_p) if rg is not None else nv.C.c_void_p(0), nv.i32(int(rg.shape[0]) if rg is not None else 0),
+                    nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
         else:
           nv.call("ps_mt19937_random_sample", nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(skip)), nv.i64(int(n)),
                 nv.ptr(out), nv.ptr(st_out), nv.ptr(pos_out), nv.ptr(polys),

@@ -115,7 +115,15 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """torch's current HIP stream of the current device as a C pointer.  (torch.cuda.current_stream() builds a python Stream object
+    through three layers of device-index helpers: 9 us a call, 14 calls per step -- a quarter of a sharded step's host time.)"""
+    if _raw_stream is not None and _get_device is not None:
+        return C.c_void_p(_raw_stream(_get_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -117,14 +117,15 @@ def _nodes_tensor(nodes, device, num_nodes):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
-def draw_numpy_uniforms(n, device, defer_state=False, raw=False):
+def draw_numpy_uniforms(n, device, defer_state=False, raw=False, ranges=None):
     """n doubles of the process-global legacy numpy stream, exactly what n sequential
     `np.random.choice(..., p=...)` calls consume (utils/random_walk.py:79), staged to HBM.
     defer_state: see dense.mt19937_random_sample(advance='defer').  raw=True: the caller can consume the stream as raw
-    MT19937 words (PS_RNG_STREAM_RAW); returns (tensor, is_raw) -- short requests are drawn on the host as doubles."""
+    MT19937 words (PS_RNG_STREAM_RAW); returns (tensor, is_raw) -- short requests are drawn on the host as doubles.
+    ranges (raw): the runs of uniform indices the caller reads (dense.mt19937_random_sample); the rest stays unwritten."""
     if n >= (1 << 17):
         from . import dense                    # same stream, generated on the device (jump-ahead chunks)
-        t = dense.mt19937_random_sample(int(n), device, advance="defer" if defer_state else True, raw=raw)
+        t = dense.mt19937_random_sample(int(n), device, advance="defer" if defer_state else True, raw=raw, ranges=ranges if raw else None)
         return (t, True) if raw else t
     if raw:
         return draw_numpy_uniforms(n, device, defer_state), False
@@ -235,7 +236,21 @@ def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0,
             uoff = uoff_all if stream_nodes is None else uoff_all[lo:lo + B].contiguous()
             mode = nv.PS_RNG_STREAM
             if uniforms is None:
-                uniforms, is_raw = draw_numpy_uniforms(layers * stride, dev, defer_state=defer_state, raw=True)
+                # an item shard reads only the stream positions of its own start nodes: one run per layer (its bounds are, like
+                # the offsets, a property of the graph: fetched once and kept)
+                runs = None
+                if stream_nodes is not None and B > 0 and B < uoff_all.numel():
+                    rkey = None if key is None else key + ("run", lo, B)
+                    if rkey is not None and rkey in cache:
+                        u_lo, u_hi = cache[rkey]
+                    else:
+                        u_lo = int(uoff_all[lo].item())
+                        u_hi = int(uoff_all[lo + B].item()) if lo + B < uoff_all.numel() else stride
+                        if rkey is not None:
+                            cache[rkey] = (u_lo, u_hi)
+                    if layers <= 3:
+                        runs = [(r * stride + u_lo, r * stride + u_hi) for r in range(layers)]
+                uniforms, is_raw = draw_numpy_uniforms(layers * stride, dev, defer_state=defer_state, raw=True, ranges=runs)
                 mode = nv.PS_RNG_STREAM_RAW if is_raw else nv.PS_RNG_STREAM
         elif rng == "philox":
             uoff, uniforms, mode = None, None, nv.PS_RNG_PHILOX

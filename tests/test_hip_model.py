@@ -264,6 +264,20 @@ def test_device_mt19937_matches_numpy():
         rs = np.random.RandomState(seed)
         rs.random_sample(burn)
         assert np.array_equal(outs[0][0].cpu().numpy(), rs.random_sample(n)) and rs.random_sample() == outs[0][2]
+    # ranged requests (a rank of an item-sharded job reads only its own start nodes' stream positions): the words of the runs
+    # equal the whole stream's, and the state handed back is the post-whole-stream state
+    n = 23_618_800
+    np.random.seed(5)
+    full = dense.mt19937_random_sample(n, "cuda", raw=True)
+    tail = np.random.random_sample()
+    h = n // 2
+    for runs in ([(0, n // 8)], [(3 * (h // 8), 4 * (h // 8)), (h + 3 * (h // 8), h + 4 * (h // 8))], [(n - 1000, n)], [(5, 6)],
+                 [(n // 3, n // 3 + 10), (n // 3 + 70_000, n // 3 + 70_010), (n - 5, n)], [(h - 40_000, h + 40_000)], [(0, n)]):
+        np.random.seed(5)
+        part = dense.mt19937_random_sample(n, "cuda", raw=True, ranges=runs)
+        assert np.random.random_sample() == tail, runs
+        for lo, hi in runs:
+            assert torch.equal(part[2 * lo:2 * hi], full[2 * lo:2 * hi]), (runs, lo, hi)
     # chunk windows by doubling (no radix-16 table) and by radix-16 rounds agree, incl. > 16 and > 256 chunks
     for n in (3_000_000, 20_000_000):
         np.random.seed(21)
