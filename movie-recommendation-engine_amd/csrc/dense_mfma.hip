@@ -856,6 +856,9 @@ int launch_persistent(const GemmArgs &g, hipStream_t st) {
 template <int EPI, bool FAST>
 int launch_gemm_v(const GemmArgs &g, hipStream_t st) {
     // aligned operands: the persistent form of the same tiles (PS_GEMM_PERSIST=0: the one-tile-per-workgroup kernels)
+    // (r03, measured and not kept: eight waves per 32 x 256 tile for shards of <= 512 row tiles -- one 32 x 32 MFMA tile per wave
+    // halves a wave's MFMA chain, but the launch then waits for the next K step's operands instead, which are only requested one
+    // step ahead: 7 381 rows 60.7 -> 55.8 TFLOP/s, 14 762 rows 80.4 -> 72.7, LSH projection 83 -> 69.)
     if (FAST && g.grp == nullptr && g.N > 128 && (g.x2 == nullptr || g.K2 % 32 == 0)) {
         const char *pe = getenv("PS_GEMM_PERSIST");
         const bool persist = pe == nullptr || atoi(pe) != 0;

@@ -15,6 +15,8 @@ exercise the orchestration under gloo.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -187,7 +189,7 @@ class ShardedPinSage:
         self.lo, self.hi, self.chunk = shard_range(self.M, self.rank, self.world)
         self._nodes = {}                   # device -> arange(lo, hi): made once, not per step
         self.overlap_sampling = False      # measured: no gain on MI355X (2.69 vs 2.65 ms per pass)
-        self.overlap_input_proj = False    # numpy-stream mode: input projection beside the MT19937 generator -- measured r03: no
+        self.overlap_input_proj = os.environ.get("PS_OVERLAP_INPUT_PROJ") == "1"    # numpy-stream mode: input projection beside the MT19937 generator -- measured r03: no
                                            # gain (1.224 vs 1.213 ms per embed pass: the 46 us GEMM hides, the stream hand-over costs it back)
         self.fuse_self = True
         self._streams = {}
