@@ -142,8 +142,9 @@ int ps_uniform_offsets(const int64_t *rowptr, int64_t V, const int64_t *starts, 
  * jump-ahead); with NULL polynomials / workspace a single workgroup generates the stream serially (skip must be 0).
  * radix_polys uint32[radix_levels, 31, 624] (entry (i, j-1) = t^(j * 2^(c + 5i)) mod phi, optional): the chunk windows
  * are then produced in radix-32 rounds instead of by doubling.
- * window_polys uint32[n_window, 624] (row j-1 = t^(j * 2^c) mod phi, optional; mtjump.window_polynomials): requests of
- * 33 .. n_window + 1 chunks get ALL their windows in one product round from the first window.
+ * window_polys uint32[n_window, 624] (row j-1 = t^(j * 2^c + s) mod phi, s = ps_mt19937_window_shift() -- the generator
+ * expands the sequence s words back from the first window as well as forwards; optional; mtjump.window_polynomials):
+ * requests of 33 .. n_window + 1 chunks get ALL their windows in one product round from the first window.
  * ranges (ps_mt19937_raw_stream only; a HOST array int64[n_ranges][2], n_ranges <= 3, NULL = everything): runs [lo, hi) of
  * uniform indices the caller will read -- a rank of an item-sharded job passes the stream positions of ITS start nodes
  * (one run per GCN layer); only those words of `raw` (and the state hand-back) are generated, the rest of the buffer is
@@ -152,6 +153,7 @@ int ps_uniform_offsets(const int64_t *rowptr, int64_t V, const int64_t *starts, 
  * PS_RNG_STREAM_RAW -- the walk kernel tempers and combines the two words of a uniform itself, which saves the conversion
  * pass (65 us and 190 MB of traffic per 23.6 M doubles).  Needs the jump polynomials (n >= 2^17). */
 int ps_mt19937_chunk_log2(void);
+int ps_mt19937_window_shift(void);
 int ps_mt19937_raw_stream(const uint32_t *state_in, int pos_in, int64_t n, uint32_t *raw, uint32_t *state_out,
                           int32_t *pos_out, const uint32_t *jump_polys, int jump_levels, const uint32_t *radix_polys,
                           int radix_levels, const uint32_t *window_polys, int n_window, const int64_t *ranges,

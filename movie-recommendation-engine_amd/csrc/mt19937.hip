@@ -114,7 +114,10 @@ __device__ __forceinline__ uint32_t untwist(uint32_t tmp) {
 //   p[i], i = 1..226 needs p[i+397], p[i+396] -- both of the first kind -- and o[i], o[i-1];
 //   p[227] and p[0] need p[623] (Y(226) = untwist(o[226] ^ p[623]), Y(-1) = untwist(p[623] ^ p[396])), of the first kind too.
 // Thread t < 227 produces p[t + 397] and p[t] (recomputing p[t + 396] for itself: 9 old words), thread t < 170 also p[227 + t];
-// thread 0's two extra words are broadcast reads for everybody.
+// thread 0's two extra words are broadcast reads for everybody.  (Measured and not kept: three untwists per thread with the
+// neighbours' Y values taken by DPP wave_shr:1, waves overlapping by two lanes -- bit-identical, fewer instructions, but the chunk
+// launch took 54.2 instead of 50.3 us and the begin kernel 9.7 instead of 8.8 in the same process: the wave-wide shifts sit in
+// the block's dependent chain.)
 template <typename Emit>
 __device__ __forceinline__ void prev_block_emit(const uint32_t *o, uint32_t *p, int t, Emit emit) {
     constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu;
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256) void mt_prepare_kernel(const uint32_t *state_i
 constexpr int JP = 24;                                   // workgroups per jump
 constexpr int PW = MT_N / JP;                            // polynomial words per part (78 -> 2496 bits)
 constexpr int SEQ_PAD = 34 * MT_N;                       // expanded sequence per source, whole blocks
+constexpr int XB = 17;                                   // one-round scheme: blocks of it that lie BEFORE the source window
 static_assert(SEQ_PAD >= DEG + MT_N && JP * PW == MT_N, "jump geometry");
 
 __device__ __forceinline__ uint32_t load_window_word(const uint32_t *parts, int nparts, int t) {
@@ -304,7 +308,7 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 
-constexpr int KS_TOTAL = 315;                 // 64-bit k steps: 312 (19 968 polynomial bits) padded to a multiple of 5 x parts
+constexpr int KS_TOTAL = 320;                 // 64-bit k steps: 312 (19 968 polynomial bits) padded so that 4 .. 32 slices have a multiple of 5 steps
 constexpr int PLW = SEQ_PAD / 32;             // dwords per bit plane of an expanded sequence
 constexpr int JT = 20, JG = 10;               // 32-lag tiles (624 lags = 19.5 tiles), lag tiles per wave
 constexpr int MF_PLANES = 2;                  // bit planes per workgroup (two waves each)
@@ -326,40 +330,54 @@ __global__ __launch_bounds__(256) void mt_pack_polys_kernel(const uint32_t *__re
                             bits_to_fp4(word >> 24));
 }
 
-// First launch of the one-round scheme.  Workgroup 0 (when `state_in` is given): the window W1 at stream word 1 and word 0 from
-// numpy's state (= mt_prepare_kernel), W1 to plain0, and its expansion to 34 blocks (= mt_expand_kernel) -- a serial chain of
-// 36 block updates; the other workgroups meanwhile expand `ngroups` 32-row groups of the window-polynomial table into MFMA A
+// First launch of the one-round scheme.  Workgroups 0 and 1: the window W1 at stream word 1 and word 0 from numpy's state
+// (= mt_prepare_kernel; without a state the window is read from plain0), W1 to plain0, and the 34 blocks of the sequence AROUND it
+// (XB blocks before, 33 - XB after) that the window polynomials are applied to; the other workgroups meanwhile expand `ngroups` 32-row groups of the window-polynomial table into MFMA A
 // operands (= mt_pack_polys_kernel per group; product q applies table row win_of(q) - 1; q >= nrows: zero).
 __global__ __launch_bounds__(256) void mt_begin_kernel(const uint32_t *__restrict__ state_in, int pos_in, uint32_t *__restrict__ plain0,
                                                        uint32_t *__restrict__ word0, uint32_t *__restrict__ seq,
                                                        const uint32_t *__restrict__ polys, int nrows, int ngroups, uint4 *__restrict__ polyA,
                                                        WinSet ws) {
     const int t = threadIdx.x;
-    if (blockIdx.x == 0) {
-        if (state_in == nullptr) return;
+    if (blockIdx.x < 2) {
+        // workgroup 0 expands forwards from the window (blocks XB + 1 .. 33 of seq), workgroup 1 backwards (blocks XB - 1 .. 0):
+        // two chains of 16 / 17 block updates instead of one of 33; the window-polynomial table carries the offset XB * 624
+        const bool back = blockIdx.x == 1;
         __shared__ uint32_t s3[3 * MT_N];
         __shared__ uint32_t mt[2][MT_N];
-        for (int i = t; i < MT_N; i += 256) s3[i] = state_in[i];
-        __syncthreads();
-        next_block(s3, s3 + MT_N, t);
-        next_block(s3 + MT_N, s3 + 2 * MT_N, t);
-        for (int i = t; i < MT_N; i += 256) {
-            const uint32_t v = s3[pos_in + 1 + i];
-            mt[0][i] = v;
-            plain0[i] = v;
-            seq[i] = v;
+        if (state_in != nullptr) {
+            for (int i = t; i < MT_N; i += 256) s3[i] = state_in[i];
+            __syncthreads();
+            next_block(s3, s3 + MT_N, t);
+            next_block(s3 + MT_N, s3 + 2 * MT_N, t);
         }
-        if (t == 0) word0[0] = s3[pos_in];
+        for (int i = t; i < MT_N; i += 256) {
+            const uint32_t v = state_in != nullptr ? s3[pos_in + 1 + i] : plain0[i];     // (no state: the window is already in plain0)
+            mt[0][i] = v;
+            if (!back) {
+                if (state_in != nullptr) plain0[i] = v;
+                seq[XB * MT_N + i] = v;
+            }
+        }
+        if (t == 0 && !back && state_in != nullptr) word0[0] = s3[pos_in];
         __syncthreads();
         int cur = 0;
-        for (int blk = 1; blk < 34; ++blk) {
-            uint32_t *dst = seq + blk * MT_N;
-            next_block_emit(mt[cur], mt[cur ^ 1], t, [&](int i, uint32_t v) { dst[i] = v; });
-            cur ^= 1;
+        if (!back) {
+            for (int blk = XB + 1; blk < 34; ++blk) {
+                uint32_t *dst = seq + blk * MT_N;
+                next_block_emit(mt[cur], mt[cur ^ 1], t, [&](int i, uint32_t v) { dst[i] = v; });
+                cur ^= 1;
+            }
+        } else {
+            for (int blk = XB - 1; blk >= 0; --blk) {
+                uint32_t *dst = seq + blk * MT_N;
+                prev_block_emit(mt[cur], mt[cur ^ 1], t, [&](int i, uint32_t v) { dst[i] = v; });
+                cur ^= 1;
+            }
         }
         return;
     }
-    const int64_t idx = (int64_t)(blockIdx.x - 1) * 256 + t;
+    const int64_t idx = (int64_t)(blockIdx.x - 2) * 256 + t;
     if (idx >= (int64_t)ngroups * KS_TOTAL * 64) return;
     const int g = (int)(idx / (KS_TOTAL * 64)), rem = (int)(idx % (KS_TOTAL * 64));
     const int ks = rem >> 6, lane = rem & 63, q = 32 * g + (lane & 31), w = 2 * ks + (lane >> 5);
@@ -531,7 +549,9 @@ __global__ __launch_bounds__(256) void mt_fold_kernel(const uint32_t *parts, uin
 constexpr int64_t HALF = CHUNK / 2;
 // The 624 words from key_w on are also the state numpy is left in: stored to state_out by whoever produces them (key_w < 1:
 // none here, mt_final_state_kernel copies them).
-// Slot blockIdx.x holds window (slot == 0 ? 0 : win_of(slot - 1)) + c0; only words of `wt` are stored.
+// Slot blockIdx.x holds window (slot == 0 ? 0 : win_of(slot - 1)) + c0; only words of `wt` are stored.  RANGED = false: one
+// wanted run (the whole-stream request): the hull [lo, hi) IS the wanted set (the general tests cost the 722-workgroup launch 6 us).
+template <bool RANGED>
 __global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, int nparts, int64_t c0, WinSet ws, Wanted wt, int64_t w_lo,
                                                        uint32_t *raw, int64_t key_w, uint32_t *state_out, int pos, int32_t *pos_out) {
     __shared__ uint32_t mt[2][MT_N];
@@ -552,6 +572,7 @@ __global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, i
     }
     if (lo >= hi) return;                                      // block-uniform
     auto wanted = [&](int64_t w) {
+        if (!RANGED) return w >= lo && w < hi;
         bool in = false;
 #pragma unroll
         for (int i = 0; i < 4; ++i) in = in || (i < wt.n && w >= wt.lo[i] && w < wt.hi[i]);
@@ -571,17 +592,21 @@ __global__ __launch_bounds__(256) void mt_chunk_kernel(const uint32_t *states, i
     }
     __syncthreads();
     auto step = [&](const uint32_t *o, uint32_t *n, int64_t w0) {
-        bool whole = false;                                    // whole block inside ONE wanted run and this half chunk, no state word in it (scalar test)
+        bool whole = !RANGED;                                  // whole block inside ONE wanted run and this half chunk, no state word in it (scalar test)
+        if (RANGED) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) whole = whole || (i < wt.n && w0 >= wt.lo[i] && w0 + MT_N <= wt.hi[i]);
-        if (whole && w0 >= h_lo && w0 + MT_N <= h_hi && (w0 + MT_N <= key_w || w0 >= key_w + MT_N)) {   // no per-word tests
+            for (int i = 0; i < 4; ++i) whole = whole || (i < wt.n && w0 >= wt.lo[i] && w0 + MT_N <= wt.hi[i]);
+        }
+        if (whole && w0 >= (RANGED ? h_lo : lo) && w0 + MT_N <= (RANGED ? h_hi : hi) && (w0 + MT_N <= key_w || w0 >= key_w + MT_N)) {   // no per-word tests
             uint32_t *dst = raw + (w0 - w_lo);
             if (back) prev_block_emit(o, n, t, [&](int i, uint32_t v) { if (!(PS_MT_DEBUG & 16) || v == 0x12345u) dst[i] = v; });
             else next_block_emit(o, n, t, [&](int i, uint32_t v) { if (!(PS_MT_DEBUG & 16) || v == 0x12345u) dst[i] = v; });
         } else {
-            bool any = false;                                  // a block on the way to the wanted words stores nothing (scalar test too:
-#pragma unroll                                                 // the per-word tests made such a chain 2.5 x slower than a stored one)
-            for (int i = 0; i < 4; ++i) any = any || (i < wt.n && w0 < wt.hi[i] && w0 + MT_N > wt.lo[i]);
+            bool any = !RANGED;                                // a block on the way to the wanted words stores nothing (scalar test too:
+            if (RANGED) {                                      // the per-word tests made such a chain 2.5 x slower than a stored one)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) any = any || (i < wt.n && w0 < wt.hi[i] && w0 + MT_N > wt.lo[i]);
+            }
             if (!any) {
                 if (back) prev_block_emit(o, n, t, [&](int, uint32_t) {});
                 else next_block_emit(o, n, t, [&](int, uint32_t) {});
@@ -658,6 +683,7 @@ Plan make_plan(int pos_in, int64_t skip, int64_t n) {
 }  // namespace
 
 extern "C" int ps_mt19937_chunk_log2(void) { return CHUNK_LOG2; }
+extern "C" int ps_mt19937_window_shift(void) { return XB * MT_N; }
 
 static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64_t n, double *out, uint32_t *raw_out,
                        uint32_t *state_out, int32_t *pos_out, const uint32_t *jump_polys, int jump_levels,
@@ -798,7 +824,17 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
     uint32_t *seqM = nullptr, *planes1 = nullptr;
     uint4 *polyAw = nullptr;
     uint16_t *PLw = reinterpret_cast<uint16_t *>(states + WSZ);
-    const int parts_w = ngroups * (32 / MF_PLANES) * 7 >= 512 ? 7 : 21;
+    // slices of the polynomial bits per (group, plane pair): the launch runs in rounds of 512 workgroups (two per CU), so pick the
+    // slicing whose last round is fullest (361 windows: 12 x 16 x 8 = 1536 = three whole rounds; 7 slices were 2.6 rounds = three)
+    int parts_w = 32;
+    {
+        double best = 1e30;
+        for (int parts = 4; parts <= 32; parts *= 2) {
+            const int64_t wgs = (int64_t)ngroups * (32 / MF_PLANES) * parts;
+            const double cost = (double)((wgs + 511) / 512) * (KS_TOTAL / parts + 4);      // rounds x (steps + a workgroup's fixed part)
+            if (wgs >= 256 && cost < best) { best = cost; parts_w = parts; }
+        }
+    }
     if (one_round) {
         char *q = reinterpret_cast<char *>(seqs);
         const char *q_end = q + align256((size_t)(Kc / 2 + 2) * SEQ_PAD * 4);
@@ -811,7 +847,7 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
     }
     const unsigned pack_blocks = (unsigned)(((int64_t)ngroups * KS_TOTAL * 64 + 255) / 256);
     if (one_round && p.c0 == 0) {
-        hipLaunchKernelGGL(mt_begin_kernel, dim3(1 + pack_blocks), dim3(256), 0, st, state_in, pos_in, plainS, word0, seqM, window_polys,
+        hipLaunchKernelGGL(mt_begin_kernel, dim3(2 + pack_blocks), dim3(256), 0, st, state_in, pos_in, plainS, word0, seqM, window_polys,
                            (int)nprod, ngroups, polyAw, ws);
         PS_CHECK_LAUNCH();
     } else {
@@ -831,12 +867,10 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
         }
         if (hipMemcpyAsync(states, cur, WSZ * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;
         if (one_round) {                                // after a skipped prefix: window c0 is in `states`, JP parts
-            hipLaunchKernelGGL(mt_begin_kernel, dim3(1 + pack_blocks), dim3(256), 0, st, (const uint32_t *)nullptr, 0, plainS, word0, seqM,
-                               window_polys, (int)nprod, ngroups, polyAw, ws);
-            PS_CHECK_LAUNCH();
             hipLaunchKernelGGL(mt_fold_kernel, dim3(3), dim3(256), 0, st, states, plainS);
             PS_CHECK_LAUNCH();
-            hipLaunchKernelGGL(mt_expand_kernel, dim3(1), dim3(256), 0, st, plainS, 1, (int64_t)0, seqM);
+            hipLaunchKernelGGL(mt_begin_kernel, dim3(2 + pack_blocks), dim3(256), 0, st, (const uint32_t *)nullptr, 0, plainS, word0, seqM,
+                               window_polys, (int)nprod, ngroups, polyAw, ws);
             PS_CHECK_LAUNCH();
         }
     }
@@ -873,7 +907,7 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
         uint4 *polyA1 = reinterpret_cast<uint4 *>(q);          q += align256((size_t)KS_TOTAL * 64 * 16);
         plainS = reinterpret_cast<uint32_t *>(q);              q += align256((size_t)K * MT_N * 4);
         // parity planes of every polynomial slice: in the JP-part window store, unused (but for window 0) in this mode
-        constexpr int PARTS_A = 21, PARTS_B = 7;
+        constexpr int PARTS_A = 32, PARTS_B = 8;
         uint16_t *PLp = reinterpret_cast<uint16_t *>(states + WSZ);
         const bool pl_fits = (size_t)PARTS_B * nsrcB * 32 * JT * 32 <= (size_t)(K - 1) * WSZ && (size_t)PARTS_A * 32 * JT * 32 <= (size_t)(K - 1) * WSZ;
         if (q <= q_end && pl_fits) {
@@ -938,8 +972,12 @@ static int mt_generate(const uint32_t *state_in, int pos_in, int64_t skip, int64
     }
     // 4. chunks -> raw words; word 0 separately
     const int64_t key_fold = p.key_w >= 1 ? p.key_w : -(int64_t)4 * MT_N;         // no stream word lies in the folded range then
-    hipLaunchKernelGGL(mt_chunk_kernel, dim3((unsigned)Kw, 2), dim3(256), 0, st, plain_states ? plainS : states, plain_states ? 1 : JP, p.c0,
-                       ws, wt, p.w_lo, raw, key_fold, state_out, p.pos_out, pos_out);
+    if (ranged)
+        hipLaunchKernelGGL(mt_chunk_kernel<true>, dim3((unsigned)Kw, 2), dim3(256), 0, st, plain_states ? plainS : states, plain_states ? 1 : JP,
+                           p.c0, ws, wt, p.w_lo, raw, key_fold, state_out, p.pos_out, pos_out);
+    else
+        hipLaunchKernelGGL(mt_chunk_kernel<false>, dim3((unsigned)Kw, 2), dim3(256), 0, st, plain_states ? plainS : states, plain_states ? 1 : JP,
+                           p.c0, ws, wt, p.w_lo, raw, key_fold, state_out, p.pos_out, pos_out);
     PS_CHECK_LAUNCH();
     if (p.w_lo == 0)
         if (hipMemcpyAsync(raw, word0, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return PS_ELAUNCH;

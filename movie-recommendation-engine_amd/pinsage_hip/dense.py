@@ -309,7 +309,8 @@ def _window_polys(dev):
         from . import mtjump
         import numpy as np
         cl2 = int(nv.lib().ps_mt19937_chunk_log2())
-        _window_polys_dev[key] = torch.from_numpy(mtjump.window_polynomials(cl2).view(np.int32)).to(dev).contiguous()
+        shift = int(nv.lib().ps_mt19937_window_shift())
+        _window_polys_dev[key] = torch.from_numpy(mtjump.window_polynomials(cl2, shift=shift).view(np.int32)).to(dev).contiguous()
     return _window_polys_dev[key]
 
 

@@ -62,21 +62,23 @@ def test_radix_polynomials_agree_with_the_binary_table():
 
 
 def test_window_polynomials_are_the_single_jumps():
-    """row j-1 = t^(j * 2^c): rows 1..31 and 32 j are the radix tables' entries, every row is the product of two smaller
-    ones, and a jump applied through the recurrence lands on the window j * 2^c words later (small c: the check walks
-    the sequence)."""
+    """row j-1 = t^(j * 2^c + shift): t^shift times the radix tables' entries for j = 1..31 and 32 j, every row the product of an
+    earlier row with an unshifted multiplier, and the sparse reduction agrees with the bit-serial one."""
     from pinsage_hip import mtjump
-    c = 17
+    c, L = 17, mtjump.WINDOW_SHIFT
     W, R = mtjump.window_polynomials(c), mtjump.radix_polynomials(c)
     assert W.shape == (mtjump.WINDOW_POLYS, 624) and W.dtype == np.uint32
-    assert all(np.array_equal(W[j - 1], R[0, j - 1]) for j in range(1, 32))
-    assert all(np.array_equal(W[32 * j - 1], R[1, j - 1]) for j in range(1, 16))
     phi = mtjump.characteristic_polynomial()
     as_int = lambda row: int.from_bytes(row.astype("<u4").tobytes(), "little")
-    for j in (33, 100, 361, 511):
-        a = j // 2
-        assert mtjump._reduce(mtjump._mul(as_int(W[a - 1]), as_int(W[j - a - 1])), phi) == as_int(W[j - 1])
-    # the sparse reduction agrees with the bit-serial one
+    shifted = lambda row: mtjump._reduce(as_int(row) << L, phi)
+    assert all(as_int(W[j - 1]) == shifted(R[0, j - 1]) for j in (1, 2, 7, 31))
+    assert all(as_int(W[32 * j - 1]) == shifted(R[1, j - 1]) for j in (1, 5, 15))
+    for j in (33, 100, 361, 511):                                  # t^(j u + L) = t^(a u + L) * t^((j - a) u), a u from the radix tables
+        a = 32 * (j // 32)
+        assert mtjump._reduce(mtjump._mul(as_int(W[j - a - 1]), as_int(R[1, a // 32 - 1])), phi) == as_int(W[j - 1])
     taps = [i for i in range(mtjump.DEG) if (phi >> i) & 1]
     p = mtjump._mul(as_int(W[76]), as_int(W[12]))
     assert mtjump._reduce_sparse(p, phi, taps) == mtjump._reduce(p, phi)
+    # unshifted table: the plain single jumps
+    W0 = mtjump.window_polynomials(c, count=40, shift=0)
+    assert all(np.array_equal(W0[j - 1], R[0, j - 1]) for j in range(1, 32)) and np.array_equal(W0[31], R[1, 0])
