@@ -455,11 +455,13 @@ __global__ __launch_bounds__(256, 2) void mt_jump_mfma_kernel(const uint32_t *__
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
     };
 
+    // accumulators start at 2^23: the sums stay integers below 2^24 (at most 19 937 ones), exact in fp32, and the mantissa of
+    // 2^23 + s IS s -- the parity is bit 0 of the register, no conversion (the epilogue was 3 instructions per value)
     v16f_t acc[JG];
 #pragma unroll
     for (int j = 0; j < JG; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 8388608.f;
     constexpr int PF = 5;                                    // A fragments in flight (k steps ahead; 2 PF must be a multiple of JG)
     v4i_t R[JG], A[PF];
 #pragma unroll
@@ -497,9 +499,13 @@ __global__ __launch_bounds__(256, 2) void mt_jump_mfma_kernel(const uint32_t *__
     uint16_t *out = PLp + ((((size_t)part * nsrc + src) * 32 + b) * JT + J0) * 64 + lane;
 #pragma unroll
     for (int jj = 0; jj < JG; ++jj) {
-        uint32_t bits = 0;
+        uint32_t bits = 0;                                   // v_alignbit: bit 0 of each value enters at bit 31, sixteen of them end in 31..16
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bits |= (((uint32_t)(int)acc[jj][r]) & 1u) << r;
+        for (int r = 0; r < 16; ++r) {
+            const float f = acc[jj][r];                      // (bit_cast of a vector ELEMENT reads element 0 in this hipcc: scalar first)
+            bits = __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, f), bits, 1);
+        }
+        bits >>= 16;
         if (!(PS_MT_DEBUG & 4) || bits == 0x12345u) out[jj * 64] = (uint16_t)bits;
     }
 }

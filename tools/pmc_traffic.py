@@ -39,6 +39,14 @@ def _gemm_epi(k):
     return int(m.group(1)) if m else -1
 
 
+def _sampler_kernel(k):
+    if not k.startswith("walk_sample_kernel"):
+        return False
+    stream = any(n.startswith("walk_sample_kernel") and n.rstrip().endswith("true>") for n in names)
+    want_stream = stream and "philox" not in label
+    return k.rstrip().endswith("true>") == want_stream if stream else True
+
+
 def per_launch(pred):
     """kernels that one call launches together (scan + merge): per-launch means add up"""
     tot = 0.0
@@ -57,8 +65,10 @@ def per_call(pred):
 
 out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps {steps} --warmup 1 --no-cpu-baseline ({label})",
        "units": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB * 1024, as reported.  Calibration (profiles/r03_config5/pmc_calibration.txt): narrow gathers (8-byte / 64-byte random reads: the sampler) count exactly one 64-byte sector per request = real fabric traffic; wide coalesced streams count at 0.50 and random 1 KiB rows at 0.28 of their bytes (GEMM operands, pooling rows: multiply before comparing with a byte count)",
-       "ps_walk_sample": per_launch(lambda k: k.startswith("walk_sample_kernel")),
-       "ps_walk_sample_layers": per_launch(lambda k: k.startswith("walk_sample_kernel")),
+       # walk_sample_kernel<NP, STREAM>: the headline (numpy-stream) step launches the STREAM = true kernel; the `other_rng_mode` leg of
+       # the same bench run launches the Philox one (listed in the .txt, not part of this figure)
+       "ps_walk_sample": per_launch(_sampler_kernel),
+       "ps_walk_sample_layers": per_launch(_sampler_kernel),
        "ps_hamming_topk_mfma": per_launch(lambda k: k.startswith("hamming_mfma_kernel") or k.startswith("bound_select_kernel")
                                           or k.startswith("slice_merge_kernel")),
        # every mt_* kernel of the one-round generator runs once per call (begin, planes, jump products, reduce, finish, chunks)
