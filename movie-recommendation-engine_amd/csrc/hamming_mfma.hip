@@ -184,6 +184,10 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
     if (t1 > a.tile_end) t1 = a.tile_end;
     const int nt = t1 > t0 ? (int)((t1 - t0 + IT - 1) / IT) : 0;     // ring entries; t0 and tiles_per_slice are multiples of IT
     const int64_t last_tile = (a.N - 1) >> 5;               // tiles from here on hold padding rows (zero nibbles)
+    // the same bound relative to this slice, as a 32-bit scalar: a 64-bit signed compare is a VECTOR instruction on this ISA
+    // (v_cmp_lt_i64 + a move), two of the ~12 instructions every tile's epilogue pays
+    const int64_t last_rel64 = last_tile - t0;
+    const int last_rel = last_rel64 > 0x7fffffff ? 0x7fffffff : last_rel64 < 0 ? 0 : (int)last_rel64;
 
     // query fragments (B operand): 16 bytes per K step, resident for the whole sweep
     v4i bq[KS];
@@ -262,19 +266,22 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
     };
     auto epilogue = [&](v16f &acc, int i) __attribute__((always_inline)) {
         const int64_t t = t0 + i;
-        if (t >= last_tile) {                               // wave-uniform, once per table: mask the padding rows of its end
+        if (i >= last_rel) {                                // wave-uniform, once per table: mask the padding rows of its end
             const int64_t left64 = a.N - t * 32;            // valid rows of this tile (<= 0: a padding tile of the last entry)
             const int left = (int)(left64 < 0 ? 0 : left64 > 32 ? 32 : left64) - 4 * lh;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if ((r & 3) + 8 * (r >> 2) >= left) acc[r] = MODE == 1 ? 0.f : NO_DOT;
         }
-        // maximum of the lane's 16 elements as a tree over the four groups of consecutive registers
-        float g[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = fmaxf(fmaxf(fmaxf(acc[4 * j], acc[4 * j + 1]), acc[4 * j + 2]), acc[4 * j + 3]);
+        // maximum of the lane's 16 elements as a TERNARY tree (v_max3_f32): triples {0,1,2} .. {12,13,14} and {15}, then two
+        // triples of those: 5 + 2 + 1 = 8 instructions (r03 first version: four groups of four, 8 + 3; every instruction of this
+        // exit costs the wave ~20 cycles -- knock-outs: collect 168 us, with this exit only 128, without any epilogue 58)
+        const float a0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), a1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
+        const float a2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), a3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
+        const float a4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]), a5 = acc[15];
+        const float mu = fmaxf(fmaxf(a0, a1), a2), mv = fmaxf(fmaxf(a3, a4), a5);
+        const float m = fmaxf(mu, mv);
         if (MODE == 0) {
-            const float m = fmaxf(fmaxf(fmaxf(g[0], g[1]), g[2]), g[3]);
             // a lane's list changes only when its new group maximum beats the list's last entry: after the first few
             // tiles that is rare, and the insertion network (2 KM instructions) runs for the whole wave only then
             if (__ballot(m > best[KM - 1]) == 0ull) return;
@@ -287,8 +294,6 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
             }
             return;
         }
-        const float m01 = fmaxf(g[0], g[1]), m23 = fmaxf(g[2], g[3]);
-        const float m = fmaxf(m01, m23);
         PS_HM_COUNT(0, 1);
         if (__ballot(m >= thr) == 0ull) return;             // the usual exit (~1/3 of the tiles at 10 000 x 59 047 x 512 bit)
         PS_HM_COUNT(1, 1);
@@ -296,15 +301,15 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
         // 64 x 16.  Every scalar branch on a vector compare costs this wave a round trip that its SIMD partner's MFMA stream
         // does not hide (the r02 version walked groups and rows with ~12 such branches: ~900 cycles per entry, 2/3 of the
         // collect pass), so the common case is straight-line: the maximum itself names its row (fraction bits) and is
-        // appended; that is complete unless a second element of the lane passes too.  Two distinct rows differ in r >> 2 or
-        // in r & 3, so a second hit exists iff the second-largest maximum over the groups {4 j ..} (g) or over the groups
-        // {j, 4 + j, 8 + j, 12 + j} (h) passes: 20 more vector instructions, one branch, and only then the walk over all rows.
-        const float sg = fmaxf(fmaxf(fminf(m01, m23), fminf(g[0], g[1])), fminf(g[2], g[3]));
-        float h[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) h[j] = fmaxf(fmaxf(fmaxf(acc[j], acc[4 + j]), acc[8 + j]), acc[12 + j]);
-        const float h01 = fmaxf(h[0], h[1]), h23 = fmaxf(h[2], h[3]);
-        const float sh = fmaxf(fmaxf(fminf(h01, h23), fminf(h[0], h[1])), fminf(h[2], h[3]));
+        // appended; that is complete unless a second element of the lane passes too.  Two distinct rows differ in r / 3 or in
+        // r % 3, so a second hit exists iff the second-largest maximum over the triples {3 j ..} (sg: the smaller of the two
+        // upper maxima or the median of a triple of triples) or over the residue classes {r % 3 = j} (sh: the median of their
+        // three maxima) passes: 14 more vector instructions, one branch, and only then the walk over all rows.
+        const float sg = fmaxf(fmaxf(fminf(mu, mv), __builtin_amdgcn_fmed3f(a0, a1, a2)), __builtin_amdgcn_fmed3f(a3, a4, a5));
+        const float h0 = fmaxf(fmaxf(fmaxf(acc[0], acc[3]), acc[6]), fmaxf(fmaxf(acc[9], acc[12]), acc[15]));
+        const float h1 = fmaxf(fmaxf(fmaxf(fmaxf(acc[1], acc[4]), acc[7]), acc[10]), acc[13]);
+        const float h2 = fmaxf(fmaxf(fmaxf(fmaxf(acc[2], acc[5]), acc[8]), acc[11]), acc[14]);
+        const float sh = __builtin_amdgcn_fmed3f(h0, h1, h2);
         const uint32_t base = (uint32_t)i * 32u + 4u * lh;
         if (__ballot(fmaxf(sg, sh) >= thr) == 0ull) {
             if (m >= thr) append_bits(__float_as_uint(m), base);
