@@ -178,15 +178,21 @@ int ps_importance_pool(const float *x, int64_t N, int H, const int32_t *ids, con
 /* ---- a6: the dense layers of PinSage.forward (model/pinsage.py:202,235-240,248-249) ---------
  * y[M,N] = epilogue( x[M,K] W[N,K]^T (+ x2[M,K2] W2[N,K2]^T) + b ), fp32 MFMA, k-ordered fma chain.
  * x2/W2 eliminate torch.cat([h_self, h_neigh]) (:238): W = lin_update.weight[:, :H], W2 = [:, H:]
- * (ldw / ldw2 = row strides of W / W2 in floats).  flags: PS_RELU, PS_L2NORM (F.normalize, eps 1e-12). */
+ * (ldw / ldw2 = row strides of W / W2 in floats).  flags: PS_RELU, PS_L2NORM (F.normalize, eps 1e-12), PS_WPERM: W (and W2)
+ * are stored in the order the kernel stages them (ps_permute_k; needs 16-byte aligned operands and K % 32 == 0, else PS_EINVAL):
+ * same results bit for bit, 32 fewer vector instructions per 64 MFMAs -- for weights that are multiplied many times. */
 #define PS_RELU 1
 #define PS_L2NORM 2
+#define PS_WPERM 4
+/* out float[rows, K] (dense) = W with every group of eight k as k 0 2 4 6 1 3 5 7 (K % 8 == 0; ld = row stride of W). */
+int ps_permute_k(const float *W, int64_t rows, int K, int ld, float *out, ps_stream_t stream);
 int ps_linear(const float *x, int64_t M, int K, const float *W, int ldw, const float *b, int N,
               const float *x2, int K2, const float *W2, int ldw2, int flags, float *y, ps_stream_t stream);
 
 /* ---- a10: LSHIndex.build/search (utils/nearest_neighbors.py:28-68 -> faiss.IndexLSH) ---------
- * codes[n, nbits/8] : bit j = ( x . A[j,:] >= 0 ), LSB-first (faiss fvec2bitvec); A float[nbits,D]. */
-int ps_lsh_encode(const float *x, int64_t N, int D, const float *A, int nbits, uint8_t *codes, ps_stream_t stream);
+ * codes[n, nbits/8] : bit j = ( x . A[j,:] >= 0 ), LSB-first (faiss fvec2bitvec); A float[nbits,D].
+ * flags: 0 or PS_WPERM (A stored by ps_permute_k). */
+int ps_lsh_encode(const float *x, int64_t N, int D, const float *A, int nbits, uint8_t *codes, int flags, ps_stream_t stream);
 
 /* Hamming k-NN over all codes: k smallest by (distance, id), ascending; id = row + id_offset.
  * dist int32[nq,k] (INT32_MAX pad), ids int64[nq,k] (-1 pad).  cs = bytes per code (multiple of 4). */

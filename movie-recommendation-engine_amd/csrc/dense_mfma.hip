@@ -137,6 +137,16 @@ __device__ __forceinline__ void stash_item(float *d, f32x4 lo, f32x4 hi) {
     *reinterpret_cast<f32x4 *>(d) = f32x4{lo[0], lo[2], hi[0], hi[2]};
     *reinterpret_cast<f32x4 *>(d + 4) = f32x4{lo[1], lo[3], hi[1], hi[3]};
 }
+// The same item of an operand that is STORED in image order (PS_WPERM: every 8-k group of a weight row as k 0 2 4 6 1 3 5 7,
+// ps_permute_k): no register moves.  The 64 x 256 tile's K step had 40 v_mov for 64 MFMAs, 32 of them for the weights, and a
+// vector instruction costs a SIMD whose matrix pipe is saturated ~13 cycles of MFMA issue (PMC: 9.2 M VALU / 3.15 M MFMA per
+// launch, pipe 63 % busy): weights are static, so the permutation is done once per parameter version instead of per K step.
+template <bool PIN>
+__device__ __forceinline__ void stash_item_stored(float *d, f32x4 lo, f32x4 hi) {
+    if (PIN) asm volatile("" : "+v"(lo), "+v"(hi));
+    *reinterpret_cast<f32x4 *>(d) = lo;
+    *reinterpret_cast<f32x4 *>(d + 4) = hi;
+}
 
 // FAST: every operand is 16-B aligned with K % BK == 0 -> unconditional float4 loads (rows past the end are
 // clamped to the last valid row; their results are never stored), so nothing branches or waits inside the
@@ -362,6 +372,7 @@ __global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(Gem
         const bool vecA = (K % 4 == 0) && (reinterpret_cast<size_t>(X) % 16 == 0);
         const bool vecB = (ldw % 4 == 0) && (reinterpret_cast<size_t>(Wp) % 16 == 0);
 
+        const bool wperm = (g.flags & PS_WPERM) != 0;                          // block-uniform
         // staging registers: the two 16-byte halves of every (row, 8-k group) item, as loaded
         f32x4 ra[A_ITEMS][2], rb[B_ITEMS][2];
         auto fetch = [&](int k0) {
@@ -414,7 +425,8 @@ __global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_kernel(Gem
                 const int it = FAST ? (tid + NT * q) % (BN * GRP) : tid + NT * q, row = it / GRP, grp = it % GRP;
                 if (!FAST && it >= BN * GRP) continue;
                 float *d = sB + row * LDS_STRIDE + grp * 8;
-                stash_item<SPREAD>(d, rb[q][0], rb[q][1]);
+                if (FAST && wperm) stash_item_stored<SPREAD>(d, rb[q][0], rb[q][1]);
+                else stash_item<SPREAD>(d, rb[q][0], rb[q][1]);
             }
         };
 
@@ -499,6 +511,7 @@ __global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_pkernel(Ge
     const int wm = wv / WN, wn = wv % WN;
     const int li = lane & 31, lh = lane >> 5;
     const int steps0 = g.K / BK, steps1 = g.x2 != nullptr ? g.K2 / BK : 0, nsteps = steps0 + steps1;
+    const bool wperm = (g.flags & PS_WPERM) != 0;                              // block-uniform
 
     f32x4 ra[A_ITEMS][2], rb[B_ITEMS][2];
     // slab s of the tile at (m0, n0): K step s of the first operand pair, or s - steps0 of the second
@@ -534,7 +547,8 @@ __global__ __launch_bounds__(WM * WN * 64, PS_GEMM_OCC) void gemm_f32_pkernel(Ge
 #pragma unroll
         for (int q = 0; q < B_ITEMS; ++q) {
             const int it = (tid + NT * q) % (BN * GRP), row = it / GRP, grp = it % GRP;
-            stash_item<SPREAD>(sB + row * LDS_STRIDE + grp * 8, rb[q][0], rb[q][1]);
+            if (wperm) stash_item_stored<SPREAD>(sB + row * LDS_STRIDE + grp * 8, rb[q][0], rb[q][1]);
+            else stash_item<SPREAD>(sB + row * LDS_STRIDE + grp * 8, rb[q][0], rb[q][1]);
         }
     };
 
@@ -911,7 +925,7 @@ int launch_gemm(const GemmArgs &g, hipStream_t st) {
     // the doubled fragment reads, the lane-half selects and the 16-bytes-per-row DMA pieces; kept because it is tested
     // bit-identical and documents the experiment): aligned operands, whole 256-column tiles, many rows
     const bool use_dma = getenv("PS_GEMM_DMA") != nullptr;
-    if (fast && use_dma && g.N % DMA_BN == 0 && g.M >= 64 * 384) {
+    if (fast && use_dma && !(g.flags & PS_WPERM) && g.N % DMA_BN == 0 && g.M >= 64 * 384) {
         static bool attr_done[64] = {};
         int devid = 0;
         if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PS_ELAUNCH;
@@ -925,6 +939,7 @@ int launch_gemm(const GemmArgs &g, hipStream_t st) {
         PS_CHECK_LAUNCH();
         return PS_OK;
     }
+    if ((g.flags & PS_WPERM) && !fast) return PS_EINVAL;      // image-order weights exist for aligned operands only (K % 32 == 0)
     return fast ? launch_gemm_v<EPI, true>(g, st) : launch_gemm_v<EPI, false>(g, st);
 }
 
@@ -969,12 +984,36 @@ extern "C" int ps_linear(const float *x, int64_t M, int K, const float *W, int l
     return PS_OK;
 }
 
-extern "C" int ps_lsh_encode(const float *x, int64_t N, int D, const float *A, int nbits, uint8_t *codes,
+// out[r][8 g + j] = W[r][8 g + p(j)], p = 0 2 4 6 1 3 5 7: the order in which the GEMM's LDS image holds an 8-k group
+__global__ void permute_k_kernel(const float *__restrict__ W, int64_t rows, int K, int ld, float *__restrict__ out) {
+    const int64_t total = rows * (K / 8);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (K / 8);
+        const int g8 = (int)(i % (K / 8));
+        const float *src = W + r * ld + g8 * 8;
+        float *dst = out + r * K + g8 * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dst[j] = src[2 * j]; dst[4 + j] = src[2 * j + 1]; }
+    }
+}
+
+extern "C" int ps_permute_k(const float *W, int64_t rows, int K, int ld, float *out, ps_stream_t stream) {
+    if (rows < 0 || K <= 0 || K % 8 != 0 || ld < K) return PS_EINVAL;
+    if (rows == 0) return PS_OK;
+    if (!W || !out) return PS_EINVAL;
+    int64_t grid = ps_cdiv(rows * (K / 8), 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(permute_k_kernel, dim3((unsigned)grid), dim3(256), 0, ps_stream(stream), W, rows, K, ld, out);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+extern "C" int ps_lsh_encode(const float *x, int64_t N, int D, const float *A, int nbits, uint8_t *codes, int flags,
                              ps_stream_t stream) {
-    if (N < 0 || D <= 0 || nbits <= 0) return PS_EINVAL;
+    if (N < 0 || D <= 0 || nbits <= 0 || (flags & ~PS_WPERM)) return PS_EINVAL;
     if (nbits % 32 != 0) return PS_EUNSUPPORTED;      // codes are written as whole 32-bit ballot words
     if (N == 0) return PS_OK;
     if (!x || !A || !codes || reinterpret_cast<size_t>(codes) % 4 != 0) return PS_EINVAL;
-    GemmArgs g{x, N, D, A, D, nullptr, 0, nullptr, 0, nullptr, nbits, 0, nullptr, codes, nbits / 8};
+    GemmArgs g{x, N, D, A, D, nullptr, 0, nullptr, 0, nullptr, nbits, flags, nullptr, codes, nbits / 8};
     return launch_gemm<1>(g, ps_stream(stream));
 }

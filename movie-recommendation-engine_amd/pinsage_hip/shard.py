@@ -159,6 +159,9 @@ class HipOps:
     def lsh_encode(self, x, A):
         return dense.lsh_encode(x, A)
 
+    def stage_weight(self, W):
+        return dense.stage_weight(W)
+
     def lsh_planes(self, codes):
         return dense.lsh_expand(codes)
 
@@ -194,6 +197,7 @@ class ShardedPinSage:
         self.fuse_self = True
         self._streams = {}
         self._fused = {}                   # layer -> (W1, b1) composed from the snapshot `params`
+        self._staged = {}                  # name -> weight in kernel staging order (snapshot too); "A": (tensor, version, staged)
 
     def refresh_weights(self, params=None):
         """Call after changing the parameter tensors (in place or by passing a new dict): drops the composed
@@ -201,11 +205,22 @@ class ShardedPinSage:
         if params is not None:
             self.P = params
         self._fused.clear()
+        self._staged.clear()
 
     def _fused_layer(self, i, H):
         if i not in self._fused:
             self._fused[i] = fused_self_update(self.ops, self.P, i, H)
         return self._fused[i]
+
+    def _w(self, key, W):
+        """The weight matrix `W` in the order the GEMM kernel stages it (dense.stage_weight), made once per parameter snapshot
+        (refresh_weights drops them); backends without staged weights get W itself."""
+        if not hasattr(self.ops, "stage_weight"):
+            return W
+        t = self._staged.get(key)
+        if t is None:
+            t = self._staged[key] = self.ops.stage_weight(W)
+        return t
 
     def _side_stream(self, dev):
         key = str(dev)
@@ -258,7 +273,7 @@ class ShardedPinSage:
             aux = self._side_stream(dev)
             aux.wait_stream(main)
             with torch.cuda.stream(aux):
-                early_h = ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
+                early_h = ops.linear(x_local, self._w("in", P["input_proj.weight"]), P["input_proj.bias"], relu=True)
                 early_ready = aux.record_event()
             early_h.record_stream(main)
         if fused:
@@ -278,11 +293,11 @@ class ShardedPinSage:
         if early_h is not None:
             torch.cuda.current_stream(dev).wait_event(early_ready)             # behind the sampling kernels enqueued above
         if x_full is not None and self.world > 1:
-            h_all = ops.linear(x_full, P["input_proj.weight"], P["input_proj.bias"], relu=True)
+            h_all = ops.linear(x_full, self._w("in", P["input_proj.weight"]), P["input_proj.bias"], relu=True)
             h = h_all[self.lo:self.hi]
             pending = _Gather(h_all)
         else:
-            h = early_h if early_h is not None else ops.linear(x_local, P["input_proj.weight"], P["input_proj.bias"], relu=True)
+            h = early_h if early_h is not None else ops.linear(x_local, self._w("in", P["input_proj.weight"]), P["input_proj.bias"], relu=True)
             pending = self.comm.gather_rows_async(h, self.chunk, "h")
         for i in range(self.num_layers):
             if side is None and not fused and i + 1 < self.num_layers:
@@ -299,15 +314,24 @@ class ShardedPinSage:
             if side is not None:
                 torch.cuda.current_stream(dev).wait_event(ready[i])
             h_neigh = ops.pool(h_full, batches[i], self.M - 1)
-            h = ops.linear(a_in, W1, b1, x2=h_neigh, W2=Wu[:, H:], relu=True, l2norm=True)
+            h = ops.linear(a_in, self._w(("l1", i), W1), b1, x2=h_neigh, W2=self._w(("l2", i), Wu[:, H:]), relu=True, l2norm=True)
             if i + 1 < self.num_layers:
                 pending = self.comm.gather_rows_async(h, self.chunk, "h")
-        return ops.linear(h, P["output_proj.weight"], P["output_proj.bias"], l2norm=True)
+        return ops.linear(h, self._w("out", P["output_proj.weight"]), P["output_proj.bias"], l2norm=True)
 
     # -- LSH: LSHIndex.build / .search (utils/nearest_neighbors.py:28-68) over code shards -------------
+    def _staged_A(self, A):
+        """the LSH rotation in kernel staging order, remade when another matrix (or a modified one) is passed"""
+        if not hasattr(self.ops, "stage_weight") or not isinstance(A, torch.Tensor):
+            return A
+        ent = self._staged.get("A")
+        if ent is None or ent[0] is not A or ent[1] != A._version:
+            ent = self._staged["A"] = (A, A._version, self.ops.stage_weight(A))
+        return ent[2]
+
     def build_index(self, emb_local, A):
         self.A = A
-        self.codes = self.ops.lsh_encode(emb_local, A)
+        self.codes = self.ops.lsh_encode(emb_local, self._staged_A(A))
         # sign planes of the local code shard for the int8-MFMA scan (backends without them scan the packed codes)
         self.planes = self.ops.lsh_planes(self.codes) if hasattr(self.ops, "lsh_planes") else None
         return self.codes
@@ -319,7 +343,7 @@ class ShardedPinSage:
         the records ([P, record] bytes, receive buffer allocated once) and ps_topk_merge_strided reads the gathered
         records in place: no stack / dtype conversion / reshape kernels around the exchange."""
         ops = self.ops
-        qc = ops.lsh_encode(q_local, self.A)
+        qc = ops.lsh_encode(q_local, self._staged_A(self.A))
         nq_local = qc.size(0)
         qc_all = self.comm.gather_rows(qc, nq_local, "qcodes")
         planes = getattr(self, "planes", None)

@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--M", type=int, default=59047)
 ap.add_argument("--env", default="")
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--staged", action="store_true", help="also time the same calls with image-order weights (dense.stage_weight) and compare the results bit for bit")
 a = ap.parse_args()
 M = a.M
 dev = torch.device("cuda")
@@ -37,6 +38,23 @@ for (K, N, K2, relu, l2) in ((128, 256, 0, True, False), (256, 256, 256, True, T
                   (lambda xx=xx, W1=W1, bb=bb, x2=x2, W2=W2, relu=relu, l2=l2: dense.linear(xx, W1, bb, x2=x2, W2=W2, relu=relu, l2norm=l2))))
 emb = torch.randn(M, 256, device=dev); A = torch.randn(512, 256, device=dev)
 cases.append(("lsh_encode d=256 nbits=512", 2.0 * M * 256 * 512, lambda: dense.lsh_encode(emb, A)))
+if a.staged:
+    staged_cases = []
+    for (K, N, K2, relu, l2) in ((128, 256, 0, True, False), (256, 256, 256, True, True), (256, 256, 0, False, True)):
+        g = torch.Generator(device="cpu").manual_seed(K + K2)
+        xx = torch.randn(M, K, generator=g).to(dev); Wt = (torch.randn(N, K + K2, generator=g) / 16).to(dev); bb = torch.randn(N, generator=g).to(dev)
+        x2 = torch.randn(M, K2, generator=g).to(dev) if K2 else None
+        W1, W2 = Wt[:, :K].contiguous(), (Wt[:, K:].contiguous() if K2 else None)
+        S1, S2 = dense.stage_weight(W1), dense.stage_weight(W2)
+        ref = dense.linear(xx, W1, bb, x2=x2, W2=W2, relu=relu, l2norm=l2)
+        got = dense.linear(xx, S1, bb, x2=x2, W2=S2, relu=relu, l2norm=l2)
+        assert torch.equal(ref, got), "staged weights changed the result"
+        staged_cases.append((f"staged linear K={K}+{K2} N={N} l2={int(l2)}", 2.0 * M * N * (K + K2),
+                             (lambda xx=xx, S1=S1, bb=bb, x2=x2, S2=S2, relu=relu, l2=l2: dense.linear(xx, S1, bb, x2=x2, W2=S2, relu=relu, l2norm=l2))))
+    SA = dense.stage_weight(A)
+    assert torch.equal(dense.lsh_encode(emb, A), dense.lsh_encode(emb, SA))
+    staged_cases.append(("staged lsh_encode d=256 nbits=512", 2.0 * M * 256 * 512, lambda: dense.lsh_encode(emb, SA)))
+    cases = [c for pair in zip(cases, staged_cases) for c in pair]
 for label, fl, fn in cases:
     best = {v: 1e9 for v in vals}
     for _ in range(a.rounds):
