@@ -264,9 +264,20 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
         cand[cnt * 64 + lane] = (ham << a.shift) | (row_base + (r & 3u) + 8u * (r >> 2));
         ++cnt;
     };
+    float dbg_sink = 0.f;
     auto epilogue = [&](v16f &acc, int i) __attribute__((always_inline)) {
+        if (PS_HM_DEBUG & 2048) {                           // experiment: the accumulators are read (the 8 maxima), no compare, no branch:
+            // what the matrix work costs.  collect 115 us (whole epilogue 159, usual exit only 125).  A build whose epilogue does NOT
+            // read them (bit 1, or ten unrelated vector instructions) lets the compiler drop every MFMA whose result is overwritten
+            // unread: its 58 / 67 us are the ring and the barriers, not a matrix-pipe floor (r03's first reading of bit 1 was wrong)
+            const float a0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), a1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
+            const float a2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), a3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
+            const float a4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]), a5 = acc[15];
+            dbg_sink = fmaxf(dbg_sink, fmaxf(fmaxf(fmaxf(a0, a1), a2), fmaxf(fmaxf(a3, a4), a5)));
+            return;
+        }
         const int64_t t = t0 + i;
-        if (i >= last_rel) {                                // wave-uniform, once per table: mask the padding rows of its end
+        if (__builtin_expect(i >= last_rel, 0)) {           // wave-uniform, once per table: mask the padding rows of its end
             const int64_t left64 = a.N - t * 32;            // valid rows of this tile (<= 0: a padding tile of the last entry)
             const int left = (int)(left64 < 0 ? 0 : left64 > 32 ? 32 : left64) - 4 * lh;
 #pragma unroll
@@ -274,8 +285,8 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
                 if ((r & 3) + 8 * (r >> 2) >= left) acc[r] = MODE == 1 ? 0.f : NO_DOT;
         }
         // maximum of the lane's 16 elements as a TERNARY tree (v_max3_f32): triples {0,1,2} .. {12,13,14} and {15}, then two
-        // triples of those: 5 + 2 + 1 = 8 instructions (r03 first version: four groups of four, 8 + 3; every instruction of this
-        // exit costs the wave ~20 cycles -- knock-outs: collect 168 us, with this exit only 128, without any epilogue 58)
+        // triples of those: 5 + 2 + 1 = 8 instructions (r03 first version: four groups of four, 8 + 3: collect 168 -> 159 us;
+        // knock-outs: matrix work + these 8 maxima alone 115 us, with this exit only 125, everything 159)
         const float a0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), a1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
         const float a2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), a3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
         const float a4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]), a5 = acc[15];
@@ -438,6 +449,7 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
         for (int u = 0; u < IT; ++u) epilogue(acc[u], (nt - 1) * IT + u);
     }
     if (PS_HM_DEBUG & 1) { if (acc[0][0] + acc[IT - 1][5] == 12345678.f) cnt = 1; }
+    if (PS_HM_DEBUG & 2048) { if (dbg_sink == 12345678.f) cnt = 1; }
 
     // ---- results ----
     if (MODE == 0) {
