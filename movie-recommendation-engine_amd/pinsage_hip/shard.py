@@ -329,11 +329,22 @@ class ShardedPinSage:
             ent = self._staged["A"] = (A, A._version, self.ops.stage_weight(A))
         return ent[2]
 
+    # Catalogues whose whole code table is at most this many bytes are searched QUERY-sharded: the table is all-gathered once
+    # per index build (SYN-25M: 3.8 MB), every rank scans its own queries over all of it and only final results are exchanged.
+    # Scanning all queries over 1 / P of a small table is what the scan is worst at (10 000 x 7 381 x 512 bit: 0.145 ms, 1 250 x
+    # 59 047: 0.079 ms, no merge pass, 1 MB instead of 11 MB of candidate records per rank at P = 8).  Larger catalogues (BASELINE
+    # config 5: 6.4 GB of codes) keep the code shards of SURVEY 8(e): there a rank's 12.5 M codes fill the scan.
+    REPLICATE_CODES_BYTES = 64 << 20
+
     def build_index(self, emb_local, A):
         self.A = A
         self.codes = self.ops.lsh_encode(emb_local, self._staged_A(A))
-        # sign planes of the local code shard for the int8-MFMA scan (backends without them scan the packed codes)
-        self.planes = self.ops.lsh_planes(self.codes) if hasattr(self.ops, "lsh_planes") else None
+        self.codes_all = None
+        if self.world > 1 and self.M * int(self.codes.size(1)) <= self.REPLICATE_CODES_BYTES:
+            self.codes_all = self.comm.gather_rows(self.codes, self.chunk, "codes")[: self.M]
+        scanned = self.codes_all if self.codes_all is not None else self.codes
+        # sign planes of the scanned code table for the fp4-MFMA scan (backends without them scan the packed codes)
+        self.planes = self.ops.lsh_planes(scanned) if hasattr(self.ops, "lsh_planes") else None
         return self.codes
 
     def search(self, q_local, k):
@@ -345,8 +356,25 @@ class ShardedPinSage:
         ops = self.ops
         qc = ops.lsh_encode(q_local, self._staged_A(self.A))
         nq_local = qc.size(0)
-        qc_all = self.comm.gather_rows(qc, nq_local, "qcodes")
         planes = getattr(self, "planes", None)
+        if self.world > 1 and getattr(self, "codes_all", None) is not None:
+            # query-sharded (small catalogue): own queries over the whole table, the finished rows exchanged in one collective
+            n = nq_local * k
+            rec = (12 * n + 15) // 16 * 16
+            mine = self.comm._buf("res", "mine", (1, rec), torch.uint8, qc.device, zero=True)
+            ids_v = mine[0, : 8 * n].view(torch.int64).view(nq_local, k)
+            dist_v = mine[0, 8 * n: 12 * n].view(torch.int32).view(nq_local, k)
+            try:
+                ops.hamming_topk(qc, self.codes_all, k, 0, planes=planes, out=(dist_v, ids_v))
+            except TypeError:                                                   # test backends: plain (q, codes, k, offset)
+                d, i = ops.hamming_topk(qc, self.codes_all, k, 0)
+                dist_v.copy_(d)
+                ids_v.copy_(i)
+            allr = self.comm.gather_rows(mine, 1, "res")                        # [P, rec] bytes, rank-major = query-major
+            P_ = self.world
+            return (allr[:, 8 * n: 12 * n].view(torch.int32).reshape(P_ * nq_local, k),
+                    allr[:, : 8 * n].view(torch.int64).reshape(P_ * nq_local, k))
+        qc_all = self.comm.gather_rows(qc, nq_local, "qcodes")
         if self.world == 1:
             return (ops.hamming_topk(qc_all, self.codes, k, self.lo, planes=planes) if planes is not None
                     else ops.hamming_topk(qc_all, self.codes, k, self.lo))

@@ -99,7 +99,14 @@ def _run(rank, world, port, out):
         assert torch.allclose(emb_f, emb, rtol=1e-5, atol=2e-6)
         codes = pipe.build_index(emb, A)
         nq_local = 8
+        assert pipe.codes_all is not None and pipe.codes_all.shape[0] == M      # small catalogue: codes replicated, queries sharded
         d, i = pipe.search(emb[:nq_local], K)
+        # the code-sharded form (large catalogues: every rank scans ALL queries over its shard, candidate records merged)
+        pipe.REPLICATE_CODES_BYTES = 0
+        pipe.build_index(emb, A)
+        assert pipe.codes_all is None
+        d2, i2 = pipe.search(emb[:nq_local], K)
+        assert torch.equal(d, d2) and torch.equal(i, i2)
         emb_all = all_gather_rows(emb, pipe.chunk)[:M]
         codes_all = all_gather_rows(codes, pipe.chunk)[:M]
         if rank == 0:
