@@ -492,7 +492,12 @@ __global__ __launch_bounds__(256, 2) void mt_jump_mfma_kernel(const uint32_t *__
             __builtin_amdgcn_sched_barrier(0);               // the request stays HERE, PF steps ahead of its use
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the ring's last (unused) requests
+    // The ring's last (unused) requests are still in flight: the wait must OWN their destination registers ("+v"), or the
+    // compiler -- for which A[] is dead after the last MFMA -- hands those VGPRs to the epilogue (store addresses!) and a late
+    // load lands on top of them.  (r03: with a bare `s_waitcnt` here, a two-process run on one GPU, where loads take longer,
+    // ended in "memory access fault: write to a read-only page" every few steps; single-process runs never showed it.)
+    static_assert(PF == 5, "one operand per ring slot below");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]) : : "memory");
     // parities: C col = lane & 31 (lag), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (polynomial).  Every lane packs the
     // parities of its 16 rows into 16 bits and stores them as they lie (one coalesced 128-byte store per lag tile);
     // mt_jump_finish_kernel picks bit r of lane (lag, row half) -- 16 ballots per tile cost 6 x the instructions

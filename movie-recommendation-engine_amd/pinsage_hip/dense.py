@@ -2,6 +2,8 @@
 LSH encode (projection + ballot bit-pack), Hamming top-k, exact dot top-k."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import native as nv
@@ -382,7 +384,10 @@ def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=
         raise RuntimeError("numpy global RNG is not MT19937")
     dev = torch.device(device)
     # pinned staging + asynchronous copy: a pageable `.to(dev)` waits for the stream, i.e. for the whole previous step
-    st_in = torch.from_numpy(key.astype(np.uint32).view(np.int32)).pin_memory().to(dev, non_blocking=True)
+    if os.environ.get("PS_MT_SYNC_UPLOAD") == "1":
+        st_in = torch.from_numpy(key.astype(np.uint32).view(np.int32)).to(dev)
+    else:
+        st_in = torch.from_numpy(key.astype(np.uint32).view(np.int32)).pin_memory().to(dev, non_blocking=True)
     st_out = torch.empty(624, dtype=torch.int32, device=dev)
     pos_out = torch.empty(1, dtype=torch.int32, device=dev)
     if raw and (skip != 0 or not parallel or n < (1 << 17)):

@@ -5,6 +5,8 @@
 (utils/random_walk.py:119-142), materialised only when python code actually looks at it."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -248,7 +250,7 @@ def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0,
                         u_hi = int(uoff_all[lo + B].item()) if lo + B < uoff_all.numel() else stride
                         if rkey is not None:
                             cache[rkey] = (u_lo, u_hi)
-                    if layers <= 3:
+                    if layers <= 3 and os.environ.get("PS_MT_RANGES", "1") != "0":       # PS_MT_RANGES=0: every rank generates the whole stream
                         runs = [(r * stride + u_lo, r * stride + u_hi) for r in range(layers)]
                 uniforms, is_raw = draw_numpy_uniforms(layers * stride, dev, defer_state=defer_state, raw=True, ranges=runs)
                 mode = nv.PS_RNG_STREAM_RAW if is_raw else nv.PS_RNG_STREAM
