@@ -82,8 +82,14 @@ class Comm:
             return _Gather(t)
         rest = tuple(t.shape[1:])
         if self.standin is not None:
+            # the local rows go into their slot; the OTHER slots are filled once, when the buffer is made, with copies of the
+            # first local rows seen, so that later kernels read data of the right kind from them (all-zero slots made the
+            # query-sharded scan of rank 1 of 2 ten times slower than the real thing: half of the table tied at one distance)
+            key = ("recv", tag, (self.world * chunk,) + rest, t.dtype, str(t.device))
+            fresh = key not in self._bufs
             out = self._buf("recv", tag, (self.world * chunk,) + rest, t.dtype, t.device, zero=True)
-            out[self.rank * chunk: self.rank * chunk + t.size(0)].copy_(t)
+            for r in (range(self.world) if fresh else (self.rank,)):
+                out[r * chunk: r * chunk + t.size(0)].copy_(t)
             return _Gather(out)
         if t.size(0) == chunk and t.is_contiguous():
             src = t                                          # full shard (every rank but possibly the last): no copy
