@@ -52,7 +52,7 @@ class Comm:
     that read it (RCCL's collective stream waits for the current stream at issue).
 
     standin=(rank, world): no process group -- this GPU plays ONE rank of `world`; a gather copies the local shard into its
-    slot of a buffer of the gathered shape (the other ranks' rows stay as they are: zeros).  What a rank computes per step is
+    slot of a buffer of the gathered shape (the other ranks' slots hold copies of the first local rows seen).  What a rank computes per step is
     then exactly what it computes in the real job (bench.py --config 5, tools/shard_sim.py); only the xGMI time is missing."""
 
     def __init__(self, group=None, standin=None):
