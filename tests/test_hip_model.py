@@ -610,3 +610,31 @@ def test_fused_norm_quotient_is_the_ieee_division(M, N):
     bad = np.argwhere(y.view(np.uint32) != want.view(np.uint32))
     assert y.dtype == np.float32 and bad.size == 0, [(int(r), int(c), float(x[r, c]), float(nrm[r]), float(y[r, c]), float(want[r, c]))
                                                       for r, c in bad[:8]]
+
+
+def test_staged_weights_are_bit_identical():
+    """PS_WPERM: weights stored once in the kernel's staging order (dense.stage_weight -> ps_permute_k) give the same bits as the
+    plain matrices for every tile shape the launcher picks (64 x 128 / 64 x 256 / 32 x 256, persistent and one-tile), with and
+    without the second operand pair, ReLU, fused row norm; the LSH projection too.  K % 32 != 0 keeps the plain path."""
+    from pinsage_hip import dense
+    g = torch.Generator().manual_seed(12)
+    for M in (59047, 20000, 7381, 65, 1):
+        for (K, N, K2, relu, l2) in ((128, 256, 0, True, False), (256, 256, 256, True, True), (256, 256, 0, False, True), (64, 96, 32, False, False)):
+            x = torch.randn(M, K, generator=g).cuda()
+            W = (torch.randn(N, K + K2, generator=g) / 8).cuda()
+            b = torch.randn(N, generator=g).cuda()
+            x2 = torch.randn(M, K2, generator=g).cuda() if K2 else None
+            W1, W2 = W[:, :K], (W[:, K:] if K2 else None)                       # views with row stride K + K2
+            S1, S2 = dense.stage_weight(W1), dense.stage_weight(W2)
+            assert isinstance(S1, dense.StagedWeight) and (W2 is None or isinstance(S2, dense.StagedWeight))
+            ref = dense.linear(x, W1, b, x2=x2, W2=W2, relu=relu, l2norm=l2)
+            got = dense.linear(x, S1, b, x2=x2, W2=S2, relu=relu, l2norm=l2)
+            assert torch.equal(ref, got), (M, K, N, K2)
+    emb = torch.nn.functional.normalize(torch.randn(5000, 256, generator=g), dim=1).cuda()
+    A = torch.randn(512, 256, generator=g).cuda()
+    assert torch.equal(dense.lsh_encode(emb, A), dense.lsh_encode(emb, dense.stage_weight(A)))
+    Wodd = torch.randn(40, 48, generator=g).cuda()                               # K = 48: not a multiple of 32 -> stays plain
+    assert dense.stage_weight(Wodd) is Wodd
+    with pytest.raises(ValueError):
+        dense.linear(torch.randn(4, 64).cuda(), dense.stage_weight(torch.randn(8, 64).cuda()), None,
+                     x2=torch.randn(4, 32).cuda(), W2=torch.randn(8, 32).cuda())
