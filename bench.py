@@ -42,6 +42,7 @@ VALU_POPCNT_PEAK = 1024 * 256 / 4 * 2.4e9
 # Indexed 1 KiB-row gathers served on-die (MI355X_MICROARCH.md, "Indexed rows"): rows every workgroup shares (an XCD's L2)
 # 16.8-18.8 TB/s chip-wide, uniformly random rows of a 38 MB Infinity-Cache-resident table 8.6 TB/s.  The pooled hidden rows
 # (M x H x 4 = 60 MB at ML-25M) are a popularity-skewed mix of both, so the upper figure is the bound when the table fits.
+RANDOM_SECTOR_PEAK = 55.4e9     # random 64-byte sectors per second beyond the L2, measured (tools/ubench/gather_rate.hip): 3.5 TB/s
 MALL_BYTES = 256 << 20
 ONDIE_GATHER_PEAK = 18.8e12
 
@@ -328,6 +329,15 @@ def main():
             if isinstance(traffic.get(n), (int, float)) and traffic[n] > 0:
                 k["counter_bytes_per_launch"] = traffic[n]
                 k["counter_GBps"] = traffic[n] / (k["avg_ms"] * 1e-3) / 1e9
+                if n in ("ps_walk_sample_layers", "ps_walk_sample"):
+                    # The sampler's gathers are one 64-byte sector each (calibrated: FETCH_SIZE counts exactly the sectors that leave
+                    # the L2), and the memory system beyond the L2 delivers RANDOM sectors at 55 G/s whatever the table size, loads
+                    # in flight or dependency (tools/ubench/gather_rate.hip, profiles/r03_gather_rate_ubench.txt; L2-resident:
+                    # 267 G/s): the bound this kernel is actually up against, next to the contract's algorithmic-bytes-over-HBM figure
+                    k["sectors_beyond_l2_per_launch"] = traffic[n] / 64.0
+                    k["random_sector_rate_Gps"] = traffic[n] / 64.0 / (k["avg_ms"] * 1e-3) / 1e9
+                    k["random_sector_peak_Gps"] = RANDOM_SECTOR_PEAK / 1e9
+                    k["frac_of_random_sector_peak"] = k["random_sector_rate_Gps"] * 1e9 / RANDOM_SECTOR_PEAK
         # `roofline`: the C-ABI call with the largest time per step, whatever bounds it; config 5 exists to show the sampler
         # where it is HBM-bound (the graph is 66 GB, far beyond the 256 MiB Infinity Cache), so there it is the sampler
         dom = max(kern, key=lambda n: kern[n]["ms_per_step"])
