@@ -42,6 +42,10 @@ VALU_POPCNT_PEAK = 1024 * 256 / 4 * 2.4e9
 # Indexed 1 KiB-row gathers served on-die (MI355X_MICROARCH.md, "Indexed rows"): rows every workgroup shares (an XCD's L2)
 # 16.8-18.8 TB/s chip-wide, uniformly random rows of a 38 MB Infinity-Cache-resident table 8.6 TB/s.  The pooled hidden rows
 # (M x H x 4 = 60 MB at ML-25M) are a popularity-skewed mix of both, so the upper figure is the bound when the table fits.
+# what a kernel that issues nothing but MFMAs reaches on this part (profiles/r01_mfma_rate_ubench.txt: 141-147 TFLOP/s fp32;
+# profiles/r02_mfma_fp4_vs_i8_probe.txt: 16.0 ns per fp4 32x32x64 per SIMD = 8.39 POP/s): reported beside the nominal peaks
+MFMA_F32_MEASURED = 145.0e12
+MFMA_FP4_MEASURED = 8.39e15
 RANDOM_SECTOR_PEAK = 55.4e9     # random 64-byte sectors per second beyond the L2, measured (tools/ubench/gather_rate.hip): 3.5 TB/s
 MALL_BYTES = 256 << 20
 ONDIE_GATHER_PEAK = 18.8e12
@@ -326,6 +330,9 @@ def main():
         except Exception:
             traffic = {}
         for n, k in kern.items():
+            if k.get("bound") == "mfma":
+                meas = MFMA_FP4_MEASURED if n == "ps_hamming_topk_mfma" else MFMA_F32_MEASURED
+                k["frac_of_measured_mfma_rate"] = k["achieved"] / meas
             if isinstance(traffic.get(n), (int, float)) and traffic[n] > 0:
                 k["counter_bytes_per_launch"] = traffic[n]
                 k["counter_GBps"] = traffic[n] / (k["avg_ms"] * 1e-3) / 1e9
