@@ -837,10 +837,11 @@ __global__ void l2norm_rows_kernel(float *y, int64_t M, int N) {   // N > 256 on
     }
 }
 
-// workgroups a persistent launch keeps resident: the occupancy of the instantiation x the CUs of the device (cached)
+// workgroups a persistent launch keeps resident: the occupancy of the instantiation x the CUs of the device.  `slots` is the
+// CALLER's cache (one per kernel instantiation: every instantiation has the same function-pointer type, so a static in here
+// would be shared by all of them -- r03's first version was, and gave every tile shape the grid of the first one used)
 template <typename K>
-int persistent_slots(K kernel) {
-    static int slots[64] = {};
+int persistent_slots(K kernel, int (&slots)[64]) {
     int dv = 0;
     if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= 64) return 0;
     if (slots[dv] == 0) {
@@ -859,7 +860,8 @@ int launch_persistent(const GemmArgs &g, hipStream_t st) {
     const int tiles_n = (int)ps_cdiv(g.N, BN);
     const int64_t ntiles = tiles_m * tiles_n;
     if (ntiles > 0x7fffffff) return PS_EUNSUPPORTED;
-    const int slots = persistent_slots(gemm_f32_pkernel<WM, WN, TM, TN, 32, EPI>);
+    static int slot_cache[64] = {};
+    const int slots = persistent_slots(gemm_f32_pkernel<WM, WN, TM, TN, 32, EPI>, slot_cache);
     if (slots <= 0) return PS_ELAUNCH;
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     hipLaunchKernelGGL((gemm_f32_pkernel<WM, WN, TM, TN, 32, EPI>), dim3(grid), dim3(256), 0, st, g, tiles_n, (int)ntiles);
@@ -872,7 +874,10 @@ int launch_gemm_v(const GemmArgs &g, hipStream_t st) {
     // aligned operands: the persistent form of the same tiles (PS_GEMM_PERSIST=0: the one-tile-per-workgroup kernels)
     // (r03, measured and not kept: eight waves per 32 x 256 tile for shards of <= 512 row tiles -- one 32 x 32 MFMA tile per wave
     // halves a wave's MFMA chain, but the launch then waits for the next K step's operands instead, which are only requested one
-    // step ahead: 7 381 rows 60.7 -> 55.8 TFLOP/s, 14 762 rows 80.4 -> 72.7, LSH projection 83 -> 69.)
+    // step ahead: 7 381 rows 60.7 -> 55.8 TFLOP/s, 14 762 rows 80.4 -> 72.7, LSH projection 83 -> 69.  Nor is it the operand latency:
+    // a persistent variant that requests the slabs TWO K steps ahead into two register sets was equal at 7 381 rows (61.6 / 61.2) and
+    // 4-12 % slower at 14 762 / 20 000; a shard-sized tile is bound by its own serial step: two barriers, the staging write, the
+    // first fragment reads and 32 MFMAs per wave with nobody else on the CU to fill the gaps.)
     if (FAST && g.grp == nullptr && g.N > 128 && (g.x2 == nullptr || g.K2 % 32 == 0)) {
         const char *pe = getenv("PS_GEMM_PERSIST");
         const bool persist = pe == nullptr || atoi(pe) != 0;
