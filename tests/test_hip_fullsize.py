@@ -1,7 +1,12 @@
-"""BASELINE-size runs (SYN-25M: 59 047 items, 162 541 users, 50 M directed edges) checked through
-size-independent properties -- the oracle cannot finish these sizes in seconds, so: structural invariants of
-the CSR/CDF, sampler invariants + determinism + batching/shard invariance, encode->search round trips,
-sharded search == unsharded search."""
+"""BASELINE-size runs (SYN-25M: 59 047 items, 162 541 users, 50 M directed edges).
+
+Oracle parity at full size (`test_full_catalogue_equals_the_oracle`: the multithreaded C oracle does the whole catalogue --
+every start item, both GCN layers, the pooled forward, LSH encode, thousands of queries -- in seconds): sampled ids / visit
+counts / fp64 weights, LSH codes and top-k (distance, id) bit-exact in both RNG modes, embeddings to 1e-5.  Beside it the
+size-independent properties: structural invariants of the CSR / CDF, sampler invariants + determinism + batching / shard
+invariance, encode -> search round trips, sharded search == unsharded search."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -17,6 +22,95 @@ def big():
     ei, ew = synth.bipartite_ratings(**synth.ML25M, device=dev)
     g = DeviceGraph(ei, ew)
     return g, ei, ew
+
+
+@pytest.fixture(scope="module")
+def host_graph(big):
+    """host copy of the device-built CSR + CDF for the C oracle (the build itself is held to the oracle's by
+    test_hip_sampler.py::test_csr_cdf_bit_exact_vs_oracle and, below, on the heaviest rows)"""
+    from oracle import c_oracle as co
+    g = big[0]
+    return co.Graph.from_arrays(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.cdf.cpu().numpy())
+
+
+def _oracle_threads():
+    from oracle import c_oracle as co
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, co.max_threads(), 64))
+
+
+@pytest.mark.parametrize("T,D,nbits", [(10, 128, 256), (50, 256, 512), (10, 256, 512)])   # BASELINE configs 2, 3, the headline
+def test_full_catalogue_equals_the_oracle(big, host_graph, T, D, nbits):
+    """Every start item of SYN-25M x 2 GCN layers against the C oracle (reference utils/random_walk.py:85-142,
+    model/pinsage.py:217-249, utils/nearest_neighbors.py:28-68): neighbour ids, visit counts, nvalid and the fp64
+    importance weights bit-exact in Philox mode and in the reference's np.random stream mode (incl. the np.random state
+    afterwards), embeddings through the class surface (PinSage.get_embeddings) within 1e-5 of the oracle's forward over the
+    same samples, LSH codes of those embeddings bit-exact, top-11 (distance, id) of 4 096 queries over all codes bit-exact
+    (LSHIndex.build / .search)."""
+    from oracle import c_oracle as co
+    from pinsage_hip import sampling
+    from utils.nearest_neighbors import LSHIndex, lsh_rotation_matrix
+    from utils.random_walk import RandomWalkSampler
+    from model.pinsage import PinSage
+    g = big[0]
+    cg = host_graph
+    M, W, L, LAYERS, k = 59047, 100, 2, 2, 11
+    thr = _oracle_threads()
+    nodes = np.arange(M)
+
+    def same(batch, ref):
+        ids, counts, nv, wts = ref[:4]
+        hi, hc, hn, hw = batch.host()                         # what batch_sample_neighbors' lists are made of
+        assert np.array_equal(hi, ids) and np.array_equal(hc, counts) and np.array_equal(hn, nv)
+        valid = np.arange(T)[None, :] < nv[:, None]
+        assert np.array_equal(hw[valid], wts[valid])          # fp64: count / sum(top counts), random_walk.py:113-115
+
+    # ---- Philox mode (what item shards and config 5 use) ----
+    got = sampling.walk_sample_layers(g, range(M), T, LAYERS, W, L, rng="philox", seed=42, call=0)
+    for call in range(LAYERS):
+        same(got[call], co.walk_sample(cg, nodes, T, L, W, philox=(42, call), threads=thr))
+    # the heaviest item row (81 K edges) and the heaviest user row are among the start nodes / second steps above; the hub
+    # rows as START nodes of a scattered batch too
+    deg = g.rowptr[1:] - g.rowptr[:-1]
+    hubs = torch.cat([torch.topk(deg[:M], 64).indices, M + torch.topk(deg[M:], 64).indices])
+    hb = sampling.walk_sample(g, hubs, T, W, L, rng="philox", seed=7, call=3)
+    same(hb, co.walk_sample(cg, hubs.cpu().numpy(), T, L, W, philox=(7, 3), threads=thr))
+    # ---- the reference's RNG mode through the class surface ----
+    torch.manual_seed(2)
+    model = PinSage(128, 256, D, LAYERS).to(g.device).eval()
+    x = torch.randn(M, 128, device=g.device)
+    smp = RandomWalkSampler.from_graph(g, L, W, rng="numpy", seed=0)
+    np.random.seed(42)
+    with torch.no_grad():
+        emb = model.get_embeddings(x, smp, T)
+    tail = np.random.random_sample()
+    rs = np.random.RandomState(42)
+    uoff, n = cg.uniform_offsets(nodes, W, L)
+    assert n == M * W * L
+    layers = [co.walk_sample(cg, nodes, T, L, W, uniforms=rs.random_sample(n), uoff=uoff, threads=thr) for _ in range(LAYERS)]
+    assert tail == rs.random_sample()                         # np.random ends where the reference leaves it
+    np.random.seed(42)
+    got = smp.sample_batches(range(M), T, LAYERS)             # the launch get_embeddings made, again
+    for r in range(LAYERS):
+        same(got[r], layers[r])
+    np.random.seed(42)
+    one = smp.sample_batch(torch.arange(M, device=g.device), T)     # and as one batch_sample_neighbors call
+    same(one, layers[0])
+    # ---- embeddings: the oracle's pooled forward over the same samples ----
+    params = {kk: v.detach().cpu().numpy() for kk, v in model.state_dict().items()}
+    ref = co.pinsage_forward(params, x.cpu().numpy(), [l[:3] for l in layers], threads=thr)
+    np.testing.assert_allclose(emb.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
+    # ---- LSH: codes of the GPU's embeddings and the scan over all of them ----
+    idx = LSHIndex(D, nbits, 16)
+    idx.build(emb)
+    A = lsh_rotation_matrix(D, nbits)
+    codes = co.lsh_encode(emb.cpu().numpy(), A, threads=thr)
+    assert np.array_equal(idx.index.codes.cpu().numpy(), codes)
+    q = np.concatenate([np.arange(2048), np.arange(2048, M, (M - 2048) // 2048)[:2048]])
+    dist, ids = idx.search(emb[torch.from_numpy(q).to(g.device)], k)
+    rd, ri = co.hamming_topk(codes[q], codes, k, threads=thr)
+    assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
+    assert ids.dtype == np.int64 and dist.dtype == np.float32
 
 
 def test_graph_invariants_full_size(big):
@@ -120,7 +214,7 @@ def test_lsh_roundtrip_and_sharded_search_full_size(D, nbits):
     assert int(torch.bitwise_and(neg, codes[:4096]).ne(0).sum()) < 16            # only exact zeros may share bits
     q = torch.arange(0, M, 7, device=dev)[:8192]
     planes = dense.lsh_expand(codes)
-    dist, ids = dense.hamming_topk(codes[q], codes, k, planes=planes)            # the int8-MFMA scan
+    dist, ids = dense.hamming_topk(codes[q], codes, k, planes=planes)            # the fp4-MFMA scan
     dpc, ipc = dense.hamming_topk(codes[q], codes, k, use_mfma=False)            # the popcount scan
     assert torch.equal(dist, dpc) and torch.equal(ids, ipc)
     assert bool((ids[:, 0] == q).all()) and bool((dist[:, 0] == 0).all())        # an item is its own nearest code
