@@ -12,8 +12,11 @@
  *  - every pointer is a DEVICE pointer (HBM) unless the parameter name starts with `h_`;
  *    buffers are caller-allocated and caller-owned; inputs are never written.
  *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
- *    synchronises, nothing allocates, no global state: calls are re-entrant and
- *    hipGraph-capturable.
+ *    synchronises, nothing allocates, no state a caller can observe: calls are re-entrant,
+ *    callable from several host threads and hipGraph-capturable.  (The only process-wide
+ *    data are per-device memos of idempotent one-time queries -- a kernel's dynamic-LDS
+ *    attribute has been set, a persistent kernel's resident-workgroup count -- held in
+ *    atomics: csrc/ps_common.h PsPerDevice.)
  *  - return value: PS_OK (0) or a negative PS_E* code; `ps_error_string` names it.
  *  - node ids are int32 on the device (V < 2^31), edge offsets int64.
  */
@@ -37,6 +40,11 @@ extern "C" {
 #define PS_RNG_PHILOX 1     /* Philox4x32-10, counter (node, walk, step/2, call): one block = two steps  */
 #define PS_RNG_STREAM_RAW 2 /* ps_walk_sample / ps_walk_sample_layers only: `uniforms` holds the stream as raw MT19937 words
                                (ps_mt19937_raw_stream): uniform i = genrand_res53(temper(word 2i), temper(word 2i+1)) */
+
+#define PS_RNG_STREAM_WALKS 3 /* ps_walk_sample only: PS_RNG_STREAM with ONE stream position per walk, uoff int64[B * W]: step s of
+                               walk w of start i reads uniforms[uoff[i * W + w] + s].  For graphs with reachable sinks, where a
+                               walk that stops early consumes fewer than L uniforms (utils/random_walk.py:65-69) and the positions
+                               are the running count of uniforms consumed by every earlier walk (host: sampling.sink_walk_offsets) */
 
 typedef void *ps_stream_t;
 
@@ -91,6 +99,7 @@ int ps_graph_stats(const int64_t *rowptr, const int32_t *col, int64_t E, int64_t
  * visit counts over walk[1:], top-T by (count desc, first-visit order), one wave per start node.
  * rng_mode PS_RNG_STREAM: step (walk w, step s) of start i reads uniforms[uoff[i] + w*L + s]
  *   (uoff int64[B]; the numpy call order on a graph without reachable sinks).
+ * rng_mode PS_RNG_STREAM_WALKS: uoff int64[B * W], one position per walk (graphs with reachable sinks; see the define).
  * rng_mode PS_RNG_PHILOX: uniforms/uoff ignored; u = philox(seed; node, w, s/2, call) words (0,1) for even s, (2,3) for odd s.
  * Out: ids int32[B,T] (-1 pad), counts int32[B,T] (0 pad), nvalid int32[B].
  * The reference's weights are counts[i,j] / sum_j counts[i,:nvalid[i]] (:113-115).
@@ -254,7 +263,10 @@ int ps_l2_topk(const float *X, int64_t N, int D, const float *Q, int64_t nq, int
  * each query visits (entries outside [0, nlist) are skipped).  The (query, list) pairs are grouped by list on the device,
  * one grouped fp32-MFMA product multiplies every list's queries with that list's rows only, and a query's top-k sweeps its
  * nprobe result rows: nq * nprobe * (list length) dot products instead of nq * N.  Same arithmetic per (query, item) as
- * ps_l2_topk: identical (dist, ids) to the masked form. */
+ * ps_l2_topk: identical (dist, ids) to the masked form.
+ * Precondition: list_ptr non-decreasing with list_ptr[0] = 0, list_ptr[nlist] = N, and max_list >= the longest list (the
+ * workspace is sized from it).  A list that breaks it is clamped ON THE DEVICE to [0, N) and to max_list rows -- its tail is not
+ * searched -- so no access ever leaves the workspace or X. */
 size_t ps_ivf_topk_workspace_bytes(int64_t nq, int64_t N, int D, int k, int nlist, int nprobe, int64_t max_list);
 int ps_ivf_topk(const float *X, int64_t N, int D, const int64_t *list_ptr, int nlist, int64_t max_list,
                 const int64_t *item_ids, const float *Q, int64_t nq, const int32_t *probes, int nprobe, int k,

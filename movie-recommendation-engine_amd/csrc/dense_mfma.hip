@@ -841,16 +841,18 @@ __global__ void l2norm_rows_kernel(float *y, int64_t M, int N) {   // N > 256 on
 // CALLER's cache (one per kernel instantiation: every instantiation has the same function-pointer type, so a static in here
 // would be shared by all of them -- r03's first version was, and gave every tile shape the grid of the first one used)
 template <typename K>
-int persistent_slots(K kernel, int (&slots)[64]) {
+int persistent_slots(K kernel, PsPerDevice &slots) {
     int dv = 0;
     if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= 64) return 0;
-    if (slots[dv] == 0) {
+    int n = slots.get(dv);
+    if (n == 0) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dv) != hipSuccess || cus <= 0) return 0;
-        slots[dv] = per_cu * cus;
+        n = per_cu * cus;
+        slots.set(dv, n);
     }
-    return slots[dv];
+    return n;
 }
 
 template <int WM, int WN, int TM, int TN, int EPI>
@@ -860,7 +862,7 @@ int launch_persistent(const GemmArgs &g, hipStream_t st) {
     const int tiles_n = (int)ps_cdiv(g.N, BN);
     const int64_t ntiles = tiles_m * tiles_n;
     if (ntiles > 0x7fffffff) return PS_EUNSUPPORTED;
-    static int slot_cache[64] = {};
+    static PsPerDevice slot_cache;
     const int slots = persistent_slots(gemm_f32_pkernel<WM, WN, TM, TN, 32, EPI>, slot_cache);
     if (slots <= 0) return PS_ELAUNCH;
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
@@ -931,13 +933,13 @@ int launch_gemm(const GemmArgs &g, hipStream_t st) {
     // bit-identical and documents the experiment): aligned operands, whole 256-column tiles, many rows
     const bool use_dma = getenv("PS_GEMM_DMA") != nullptr;
     if (fast && use_dma && !(g.flags & PS_WPERM) && g.N % DMA_BN == 0 && g.M >= 64 * 384) {
-        static bool attr_done[64] = {};
+        static PsPerDevice attr_done;
         int devid = 0;
         if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PS_ELAUNCH;
-        if (!attr_done[devid]) {
+        if (!attr_done.get(devid)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dma_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     DMA_STAGES * DMA_STAGE_BYTES) != hipSuccess) return PS_ELAUNCH;
-            attr_done[devid] = true;
+            attr_done.set(devid, 1);
         }
         dim3 grid((unsigned)ps_cdiv(g.M, DMA_BM), (unsigned)(g.N / DMA_BN));
         hipLaunchKernelGGL((gemm_dma_kernel<EPI>), grid, dim3(DMA_WAVES * 64), DMA_STAGES * DMA_STAGE_BYTES, st, g);

@@ -200,8 +200,22 @@ __global__ __launch_bounds__(256) void ivf_count_kernel(const int32_t *__restric
 // one workgroup: bc[b][l] -> the rank base of block b inside list l (exclusive scan over the blocks, in place); then, lists in
 // order, row_start[l] (first gathered row of list l, lists padded to 64 rows), slab_off[l] (first float of its slab) and the
 // grouped product's descriptors (W row offset, columns, y offset) for every 64-row block up to `max_tiles`
+// A list's (start, length) as every kernel of the inverted-file scan sees it: clamped to the slab geometry the host sized from
+// the CALLER's `max_list` and N (ps_ivf_topk is an exported entry: a max_list below the longest list or a non-monotone list_ptr
+// must not let the grouped product or the row sweep run past the slab; such input gets a truncated list, never a stray access)
+__device__ __forceinline__ void ivf_list(const int64_t *__restrict__ list_ptr, int l, int64_t max_list, int64_t N, int64_t &j0,
+                                         int64_t &n) {
+    j0 = list_ptr[l];
+    n = list_ptr[l + 1] - j0;
+    if (j0 < 0) j0 = 0;
+    if (j0 > N) j0 = N;
+    if (n < 0) n = 0;
+    if (n > max_list) n = max_list;
+    if (n > N - j0) n = N - j0;
+}
+
 __global__ __launch_bounds__(1024) void ivf_layout_kernel(int32_t *__restrict__ bc, int nblocks, const int64_t *__restrict__ list_ptr, int nlist,
-                                                          int64_t max_tiles, int32_t *__restrict__ cnt, int64_t *__restrict__ row_start,
+                                                          int64_t max_list, int64_t N, int64_t max_tiles, int32_t *__restrict__ cnt, int64_t *__restrict__ row_start,
                                                           int64_t *__restrict__ slab_off, int64_t *__restrict__ grp) {
     __shared__ int64_t tile0;
     __shared__ int64_t off0;
@@ -233,11 +247,12 @@ __global__ __launch_bounds__(1024) void ivf_layout_kernel(int32_t *__restrict__ 
     __syncthreads();
     for (int l = 0; l < nlist; ++l) {                                        // serial over lists (100 by default), tiles in parallel
         const int64_t t0 = tile0, o0 = off0;
-        const int64_t n = list_ptr[l + 1] - list_ptr[l];
+        int64_t j0, n;
+        ivf_list(list_ptr, l, max_list, N, j0, n);
         const int64_t tiles = n > 0 ? ((int64_t)cnt[l] + 63) / 64 : 0;      // an empty list needs no product
         for (int64_t t = threadIdx.x; t < tiles; t += blockDim.x) {
             if (t0 + t < max_tiles) {
-                grp[(t0 + t) * 3 + 0] = list_ptr[l];
+                grp[(t0 + t) * 3 + 0] = j0;
                 grp[(t0 + t) * 3 + 1] = n;
                 grp[(t0 + t) * 3 + 2] = o0 + t * 64 * n;
             }
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(1024) void ivf_layout_kernel(int32_t *__restrict__ 
 // row of the gathered matrix, the slab row's offset recorded
 __global__ __launch_bounds__(256) void ivf_gather_kernel(const float *__restrict__ Q, int D, const int32_t *__restrict__ probes,
                                                          int64_t npairs, int nprobe, int nlist, const int64_t *__restrict__ list_ptr,
-                                                         const int32_t *__restrict__ bc, const int64_t *__restrict__ row_start,
+                                                         int64_t max_list, int64_t N, const int32_t *__restrict__ bc, const int64_t *__restrict__ row_start,
                                                          const int64_t *__restrict__ slab_off, float *__restrict__ Qg,
                                                          int64_t *__restrict__ seg_off) {
     extern __shared__ int32_t cursor[];                                       // [nlist] cursors, then [IVF_PAIRS_PER_BLOCK] gathered rows
@@ -273,8 +288,8 @@ __global__ __launch_bounds__(256) void ivf_gather_kernel(const float *__restrict
         int64_t row = -1;
         if (p < npairs) {
             const int l = probes[p];
-            int64_t n = 0;
-            if (l >= 0 && l < nlist) n = list_ptr[l + 1] - list_ptr[l];
+            int64_t n = 0, j0 = 0;
+            if (l >= 0 && l < nlist) ivf_list(list_ptr, l, max_list, N, j0, n);
             if (n > 0) {
                 const int rank = atomicAdd(&cursor[l], 1);
                 row = row_start[l] + rank;
@@ -312,7 +327,7 @@ __global__ __launch_bounds__(256) void ivf_gather_kernel(const float *__restrict
 // the first version walked the segments one by one behind three dependent loads each and took 14 us per segment.
 __global__ __launch_bounds__(256) void ivf_row_topk_kernel(const float *__restrict__ slab, int64_t rows, const int32_t *__restrict__ probes,
                                                            int nprobe, int nlist, const int64_t *__restrict__ list_ptr,
-                                                           const int64_t *__restrict__ seg_off, const int64_t *__restrict__ item_ids,
+                                                           int64_t max_list, int64_t N, const int64_t *__restrict__ seg_off, const int64_t *__restrict__ item_ids,
                                                            int k, int kcap, const float *__restrict__ qn, const float *__restrict__ xn,
                                                            float *__restrict__ vals, int64_t *__restrict__ ids) {
     __shared__ uint64_t skeys[4 * SELQ];
@@ -334,8 +349,9 @@ __global__ __launch_bounds__(256) void ivf_row_topk_kernel(const float *__restri
                 so = seg_off[row * nprobe + pb + lane];
                 if (so >= 0) {
                     const int l = probes[row * nprobe + pb + lane];
-                    j0 = list_ptr[l];
-                    n = (int)(list_ptr[l + 1] - j0);
+                    int64_t n64;
+                    ivf_list(list_ptr, l, max_list, N, j0, n64);
+                    n = (int)n64;
                 }
             }
             float sv[2][4], xv[2][4];
@@ -558,17 +574,17 @@ extern "C" int ps_ivf_topk(const float *X, int64_t N, int D, const int64_t *list
         const int nb = (int)ps_cdiv(npairs, IVF_PAIRS_PER_BLOCK);
         hipLaunchKernelGGL(ivf_count_kernel, dim3((unsigned)nb), dim3(256), hist_lds, st, pr, npairs, nlist, bc);
         PS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(ivf_layout_kernel, dim3(1), dim3(1024), 0, st, bc, nb, list_ptr, nlist, L.max_tiles, cnt, row_start, slab_off, grp);
+        hipLaunchKernelGGL(ivf_layout_kernel, dim3(1), dim3(1024), 0, st, bc, nb, list_ptr, nlist, max_list, N, L.max_tiles, cnt, row_start, slab_off, grp);
         PS_CHECK_LAUNCH();
         hipLaunchKernelGGL(ivf_gather_kernel, dim3((unsigned)nb), dim3(256), ((hist_lds + 7) / 8 * 8) + IVF_PAIRS_PER_BLOCK * sizeof(int64_t), st, Q + q0 * D, D, pr, npairs, nprobe, nlist, list_ptr,
-                           bc, row_start, slab_off, Qg, seg);
+                           max_list, N, bc, row_start, slab_off, Qg, seg);
         PS_CHECK_LAUNCH();
         if (N > 0 && max_list > 0) {
             const int rc = psi_linear_grouped(Qg, L.max_tiles * 64, D, X, D, slab, grp, (int)max_list, stream);
             if (rc != PS_OK) return rc;
         }
         hipLaunchKernelGGL(ivf_row_topk_kernel, dim3((unsigned)ps_cdiv(rows, 4)), dim3(256), 0, st, slab, rows, pr, nprobe, nlist,
-                           list_ptr, seg, item_ids, k, kcap, qn + q0, xn, dist + q0 * k, ids + q0 * k);
+                           list_ptr, max_list, N, seg, item_ids, k, kcap, qn + q0, xn, dist + q0 * k, ids + q0 * k);
         PS_CHECK_LAUNCH();
     }
     return PS_OK;

@@ -37,10 +37,11 @@
 // vmcnt, raw s_barrier) and two register sets of item fragments (the ds_reads of entry i + 1 run under the MFMAs of entry i);
 // waves 4-7 run their tile epilogue one entry late so that the two waves of a SIMD alternate between the matrix pipe and
 // the VALU instead of meeting at both.
-// Where the time goes (r03, 10 000 x 59 047 x 512 bit, k = 11, tools/hm_probe_run.sh): sweep without any epilogue 91 us (the
-// 4.73 M MFMAs alone are 79 us at the measured 16 ns each), + the usual exit of every tile 47 us, + the hit path (2/3 of the
-// tiles have a hit in one of the wave's 1 024 elements) 100 us: with two waves per SIMD an epilogue instruction costs the
-// wave ~13-15 cycles whatever it is, so the pass is bound by the epilogue's instruction count, not by the matrix pipe.
+// Where the time goes (r03, 10 000 x 59 047 x 512 bit, k = 11; knock-out builds, tools/hm_probe_run.sh): the matrix work with only
+// the eight maxima of the epilogue 115 us (4.73 M MFMAs at the 16 ns a bare loop measures would be 74), + compare and branch of
+// the usual exit 10 us, + the hit path (2/3 of the tiles have a hit in one of the wave's 1 024 elements) 34 us.  At 256 bit the
+// matrix work halves (65 us) but the per-tile parts do not (usual exit 18 us, hit path 70 us): that pass is bound by the
+// epilogue, not by the matrix pipe.
 #include "ps_common.h"
 
 namespace {
@@ -665,6 +666,11 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     p.btiles_per_slice = ((st + bs - 1) / bs + IT - 1) / IT * IT;
     p.bslices = (int)((st + p.btiles_per_slice - 1) / p.btiles_per_slice);
     p.km = (2 * p.bslices * 4 >= 3 * k) ? 4 : (k <= 16 ? 16 : 32);
+    // 512-bit codes keep at most 16 values per lane: with KM = 32 the two fragment sets, 32 query registers and the list do not
+    // fit 256 VGPRs (52 bytes of scratch per lane in r03 = vector-memory traffic inside the counted-vmcnt ring).  Any k distinct
+    // groups bound the k-th distance, and 2 bslices x 16 >= 32 >= k values are always there; only the tightness of the bound for
+    // k > 16 with fewer than three list entries per wanted neighbour changes, never a result.
+    if (p.KS == 8 && p.km == 32) p.km = 16;
     p.sample_tiles = st;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
@@ -677,7 +683,7 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     return p;
 }
 
-// dynamic LDS beyond 64 KiB has to be allowed per kernel (idempotent; the only process-wide state this file touches)
+// dynamic LDS beyond 64 KiB has to be allowed per kernel (idempotent; remembered per device in an atomic: PsPerDevice)
 template <typename K>
 bool allow_lds(K kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) ==
@@ -692,15 +698,19 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
     const size_t lds = p.db ? tiles_lds + (size_t)WAVES * p.cap * 64 * sizeof(uint32_t)
                             : (size_t)3 * IT1 * KS * 1024 + (size_t)WAVES * p.cap * 64 * sizeof(uint32_t);
     // once per (kernel, device): one process may drive several GPUs
-    static bool lds_done[64] = {};
+    static PsPerDevice lds_done;
     int devid = 0;
     if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PS_ELAUNCH;
-    bool lds_ok = lds_done[devid];
+    bool lds_ok = lds_done.get(devid) != 0;
     if (!lds_ok) {
         lds_ok = allow_lds(hamming_mfma_kernel<KS, 0, 4, true>, 160 * 1024) && allow_lds(hamming_mfma_kernel<KS, 0, 16, true>, 160 * 1024) &&
-                 allow_lds(hamming_mfma_kernel<KS, 0, 32, true>, 160 * 1024) && allow_lds(hamming_mfma_kernel<KS, 1, 4, true>, 160 * 1024) &&
-                 allow_lds(hamming_mfma_kernel<KS, 1, 4, false>, 80 * 1024) && allow_lds(hamming_mfma_kernel<KS, 0, 4, false>, 80 * 1024);
-        lds_done[devid] = lds_ok;
+                 allow_lds(hamming_mfma_kernel<KS, 1, 4, true>, 160 * 1024);
+        if constexpr (KS < 8) lds_ok = lds_ok && allow_lds(hamming_mfma_kernel<KS, 0, 32, true>, 160 * 1024);
+        // two workgroups per CU: 256- and 512-bit codes only (make_plan: KS <= 2 always takes the one-workgroup form, whose
+        // four-tile entries do not fit 128 VGPRs -- those instantiations spilled and were never launched: not built any more)
+        if constexpr (KS >= 4)
+            lds_ok = lds_ok && allow_lds(hamming_mfma_kernel<KS, 1, 4, false>, 80 * 1024) && allow_lds(hamming_mfma_kernel<KS, 0, 4, false>, 80 * 1024);
+        lds_done.set(devid, lds_ok ? 1 : 0);
     }
     if (!lds_ok) return PS_ELAUNCH;
     a.nqb = p.nqb;
@@ -709,10 +719,22 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
     HArgs b = a;
     b.tile_begin = 0; b.tile_end = p.sample_tiles; b.tiles_per_slice = p.btiles_per_slice; b.slices = p.bslices; b.bl = bl;
     const unsigned gb = (unsigned)(p.nqb * p.bslices);
-    if (p.km == 4 && !p.db) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 4, false>), dim3(gb), dim3(512), (size_t)3 * IT1 * KS * 1024, st, b);
-    else if (p.km == 4) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 4, true>), dim3(gb), dim3(512), tiles_lds, st, b);
-    else if (p.km == 16) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 16, true>), dim3(gb), dim3(512), tiles_lds, st, b);
-    else hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 32, true>), dim3(gb), dim3(512), tiles_lds, st, b);
+    bool launched = false;
+    if constexpr (KS >= 4) {
+        if (p.km == 4 && !p.db) {
+            hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 4, false>), dim3(gb), dim3(512), (size_t)3 * IT1 * KS * 1024, st, b);
+            launched = true;
+        }
+    }
+    if constexpr (KS < 8) {
+        if (!launched && p.km == 32) {
+            hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 32, true>), dim3(gb), dim3(512), tiles_lds, st, b);
+            launched = true;
+        }
+    }
+    if (!launched && p.km == 4) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 4, true>), dim3(gb), dim3(512), tiles_lds, st, b);
+    else if (!launched && p.km == 16) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 16, true>), dim3(gb), dim3(512), tiles_lds, st, b);
+    else if (!launched) return PS_EINVAL;
     PS_CHECK_LAUNCH();
     int64_t gs = ps_cdiv(nq, 4);
     if (gs > 4096) gs = 4096;
@@ -722,8 +744,14 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
     a.tile_begin = 0; a.tile_end = p.tiles; a.tiles_per_slice = p.tiles_per_slice; a.slices = p.slices; a.thr0 = thr0;
     a.list_base = 0;
     const unsigned gc = (unsigned)(p.nqb * p.slices);
-    if (p.db) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 4, true>), dim3(gc), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 4, false>), dim3(gc), dim3(512), lds, st, a);
+    bool collected = false;
+    if constexpr (KS >= 4) {
+        if (!p.db) {
+            hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 4, false>), dim3(gc), dim3(512), lds, st, a);
+            collected = true;
+        }
+    }
+    if (!collected) hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 4, true>), dim3(gc), dim3(512), lds, st, a);
     PS_CHECK_LAUNCH();
     return PS_OK;
 }

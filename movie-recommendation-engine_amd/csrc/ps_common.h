@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/pinsage_hip.h"
 
 #define PS_WAVE 64
@@ -13,6 +14,16 @@
     } while (0)
 
 static inline hipStream_t ps_stream(ps_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Per-device results of one-time host queries (function attributes set, resident-workgroup counts).  The work behind them is
+// idempotent, so two host threads that make a first call at the same time merely both do it; the slots are atomics so that this
+// repeat is the ONLY consequence (no torn or stale read): the library keeps no state a caller could observe
+// (include/pinsage_hip.h).  Zero-initialised statics; 0 = not known yet.
+struct PsPerDevice {
+    std::atomic<int> v[64];
+    int get(int dev) const { return v[dev].load(std::memory_order_acquire); }
+    void set(int dev, int x) { v[dev].store(x, std::memory_order_release); }
+};
 
 static inline int64_t ps_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -357,7 +357,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         PS_WS_STAMP(0);
         constexpr bool stream = STREAM;
         const bool raw = a.rng_mode == PS_RNG_STREAM_RAW;
-        const int64_t ubase0 = stream ? uniform_i64(a.uoff[i]) : 0;
+        // PS_RNG_STREAM_WALKS (graphs with reachable sinks): uoff holds one stream position PER WALK, [B * W] -- a walk that stops at a
+        // sink consumes fewer than L uniforms (utils/random_walk.py:68-69), so the positions are not a multiple of W * L apart
+        const bool perwalk = stream && a.rng_mode == PS_RNG_STREAM_WALKS;
+        const int64_t ubase0 = (stream && !perwalk) ? uniform_i64(a.uoff[i]) : 0;
 
         // ---------------- walk phase: all rounds, the start row is staged once ----------
         for (int j = lane; j < R * NP * 64; j += 64) posb_all[j] = -1;
@@ -407,6 +410,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                         const uint32_t a0 = st ? pwA.z : pwA.x, a1 = st ? pwA.w : pwA.y, b0 = st ? pwB.z : pwB.x, b1 = st ? pwB.w : pwB.y;
                         if (aliveA) uA = ((double)(mt_temper(a0) >> 5) * 67108864.0 + (double)(mt_temper(a1) >> 6)) * (1.0 / 9007199254740992.0);
                         if (aliveB) uB = ((double)(mt_temper(b0) >> 5) * 67108864.0 + (double)(mt_temper(b1) >> 6)) * (1.0 / 9007199254740992.0);
+                    } else if (perwalk) {
+                        if (aliveA) uA = a.uniforms[a.uoff[i * a.W + wA] + st];
+                        if (aliveB) uB = a.uniforms[a.uoff[i * a.W + wB] + st];
                     } else {
                         if (aliveA) uA = stream_uniform(a.uniforms, ubase + (int64_t)wA * a.L + st, raw);
                         if (aliveB) uB = stream_uniform(a.uniforms, ubase + (int64_t)wB * a.L + st, raw);
@@ -633,8 +639,10 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
     if (B < 0 || W <= 0 || L <= 0 || T <= 0 || V < 0 || rounds <= 0 || rounds > 8 || round_stride < 0) return PS_EINVAL;
     if (B == 0) return PS_OK;
     if (!rowptr || !col || !cdf || !starts || !ids || !counts || !nvalid) return PS_EINVAL;
-    if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX && rng_mode != PS_RNG_STREAM_RAW) return PS_EINVAL;
+    if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX && rng_mode != PS_RNG_STREAM_RAW && rng_mode != PS_RNG_STREAM_WALKS)
+        return PS_EINVAL;
     if (rng_mode != PS_RNG_PHILOX && (!uniforms || !uoff)) return PS_EINVAL;
+    if (rng_mode == PS_RNG_STREAM_WALKS && rounds != 1) return PS_EUNSUPPORTED;    // per-walk positions: one sample per launch
     if ((nodeinfo == nullptr) != (guide == nullptr)) return PS_EINVAL;
     if (packed && !nodeinfo) return PS_EINVAL;
     if (buckets && (!nodeinfo || reinterpret_cast<size_t>(buckets) % 64 != 0)) return PS_EINVAL;
@@ -666,15 +674,15 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
 #define PS_WS_LAUNCH(NP_)                                                                                                      \
     do {                                                                                                                       \
         if (lds > 64 * 1024) {                                                                                                 \
-            static bool done[64] = {};                                                                                         \
+            static PsPerDevice done;                                                                                           \
             int dv = 0;                                                                                                        \
             if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= 64) return PS_ELAUNCH;                                      \
-            if (!done[dv]) {                                                                                                   \
+            if (!done.get(dv)) {                                                                                               \
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(walk_sample_kernel<NP_, false>),                        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||               \
                     hipFuncSetAttribute(reinterpret_cast<const void *>(walk_sample_kernel<NP_, true>),                         \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PS_ELAUNCH; \
-                done[dv] = true;                                                                                               \
+                done.set(dv, 1);                                                                                               \
             }                                                                                                                  \
         }                                                                                                                      \
         if (rng_mode == PS_RNG_PHILOX)                                                                                         \

@@ -405,6 +405,11 @@ def mt19937_random_sample(n, device, skip=0, advance=True, parallel=True, radix=
     rg = np.ascontiguousarray(np.asarray(ranges, dtype=np.int64).reshape(-1, 2)) if ranges is not None and len(ranges) else None
     if rg is not None and rg.shape[0] > 3:
         rg = None                                                    # more runs than the planner takes: generate everything
+    if rg is not None and os.environ.get("PS_MT_POISON") == "1":
+        # debug aid (tests): words outside the requested runs stay unwritten, and the caching allocator readily hands back a
+        # block that still holds a same-seed stream from an earlier call -- a kernel that read outside its runs would then see
+        # correct-looking words.  Poisoned, any such read changes the sampled ids deterministically.
+        out.fill_(-1)
     with torch.cuda.device(dev):
         if raw:
             nv.call("ps_mt19937_raw_stream", nv.ptr(st_in), nv.i32(int(pos)), nv.i64(int(n)), nv.ptr(out), nv.ptr(st_out),

@@ -15,6 +15,7 @@ _lib = None
 PS_RNG_STREAM = 0
 PS_RNG_PHILOX = 1
 PS_RNG_STREAM_RAW = 2
+PS_RNG_STREAM_WALKS = 3
 PS_RELU = 1
 PS_L2NORM = 2
 PS_WPERM = 4

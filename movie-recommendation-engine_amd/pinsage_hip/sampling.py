@@ -138,10 +138,60 @@ def draw_numpy_uniforms(n, device, defer_state=False, raw=False, ranges=None):
     return t.to(device, non_blocking=True)
 
 
+def sink_walk_offsets(graph, starts, W, L, uniforms):
+    """Stream position of every walk, int64[B * W], on a graph with REACHABLE SINKS, plus the number of uniforms the batch
+    consumes.  The reference breaks a walk at a node without out-edges before drawing (utils/random_walk.py:65-69), so a walk
+    consumes between 0 and L uniforms and walk j starts at the running count of uniforms consumed by every earlier walk:
+    off_j = sum_{i<j} steps_i, steps_j = f_j(off_j).  That recurrence has exactly one solution, and it is found in parallel as a
+    fixpoint: walk all B * W walks from guessed positions (ps_walk_paths), count the steps they took, prefix-sum, repeat until
+    the counts reproduce themselves.  Every pass makes at least one more leading walk final, so it terminates; where the
+    number of steps is decided by the graph rather than by the draw (e.g. every walk from a user lands on an item that is a
+    sink) two or three passes are enough.  Exact, slower than the sink-free path, and only taken by graphs that need it."""
+    dev = graph.device
+    B = int(starts.numel())
+    walks = starts.repeat_interleave(W).contiguous()
+    ok = (starts >= 0) & (starts < graph.V)
+    deg = torch.zeros(B, dtype=torch.int64, device=dev)
+    deg[ok] = graph.rowptr[starts[ok] + 1] - graph.rowptr[starts[ok]]
+    steps = ((deg > 0).to(torch.int64) * L).repeat_interleave(W)
+    paths = torch.empty((B * W, L), dtype=torch.int32, device=dev)
+    off = torch.zeros(B * W, dtype=torch.int64, device=dev)
+    for _ in range(B * W + 2):
+        off = (torch.cumsum(steps, 0) - steps).contiguous()
+        if B * W == 0:
+            break
+        nv.call("ps_walk_paths", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
+                nv.ptr(walks), nv.i64(B * W), nv.i32(L), nv.i32(nv.PS_RNG_STREAM), nv.ptr(uniforms), nv.ptr(off),
+                nv.u64(0), nv.u32(0), nv.i32(0), nv.ptr(graph.nodeinfo), nv.ptr(graph.guide), nv.ptr(paths), nv.stream())
+        took = (paths >= 0).sum(dim=1)
+        if torch.equal(took, steps):
+            return off, int(steps.sum().item())
+        steps = took
+    return off, int(steps.sum().item())
+
+
+def _sink_stream(graph, starts, W, L, uniforms=None):
+    """(uniforms on the device, per-walk offsets) for a batch on a graph with reachable sinks; draws from np.random what the
+    reference would (at most one uniform per step; the global state ends exactly where the reference leaves it)."""
+    dev = graph.device
+    B = int(starts.numel())
+    given = uniforms is not None
+    if not given:
+        state = np.random.get_state()
+        host = np.random.random_sample(B * W * L + 1)          # the most the batch can consume (+1: never an empty buffer)
+        uniforms = torch.from_numpy(host).to(dev)
+    off, total = sink_walk_offsets(graph, starts, W, L, uniforms)
+    if not given:
+        np.random.set_state(state)
+        np.random.random_sample(total)                           # advance the global stream by what was really consumed
+    return uniforms, off
+
+
 def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None, use_guide=True, use_packed=True, use_buckets=True,
                 stream_nodes=None):
     """batch_sample_neighbors on the device.  rng='numpy': the global numpy stream (bit-exact with
-    the reference; needs a graph without reachable sinks); rng='philox': counter-based.
+    the reference; graphs with reachable sinks take the per-walk stream positions of sink_walk_offsets);
+    rng='philox': counter-based.
     `uniforms` (device fp64) overrides the numpy draw (tests).  `stream_nodes` (rng='numpy' only): the complete
     start-node sequence of the logical batch this call is a contiguous slice of (item shards): the stream offsets
     are computed over all of them and the whole batch's uniforms are drawn, so the ids/counts equal the matching
@@ -154,12 +204,17 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
     nvalid = torch.empty(B, dtype=torch.int32, device=dev)
     L_ = nv.lib()
     with torch.cuda.device(dev):
-        if rng == "numpy":
-            if graph.has_reachable_sink:
-                raise NotImplementedError(
-                    "rng='numpy' needs a graph in which every edge points at a node with out-edges (true for "
-                    "the reference's bidirectional graph builders); on graphs with reachable sinks the "
-                    "reference's RNG consumption is data dependent -- use rng='philox'")
+        if rng == "numpy" and graph.has_reachable_sink:
+            # data-dependent RNG consumption (utils/random_walk.py:65-69): per-walk stream positions by fixpoint
+            if stream_nodes is not None:
+                all_nodes, lo = stream_nodes
+                all_t = _nodes_tensor(all_nodes, dev, graph.V)
+                uniforms, off_all = _sink_stream(graph, all_t, W, L, uniforms)
+                uoff = off_all[lo * W:(lo + B) * W].contiguous()
+            else:
+                uniforms, uoff = _sink_stream(graph, starts, W, L, uniforms)
+            mode = nv.PS_RNG_STREAM_WALKS
+        elif rng == "numpy":
             total = torch.empty(1, dtype=torch.int64, device=dev)
             if stream_nodes is not None:
                 all_nodes, lo = stream_nodes
@@ -200,6 +255,16 @@ def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0,
     once.  `nodes` may be a python range (no host sync in the steady state).  defer_state=True leaves that hand-back to
     dense.finish_rng_state(), which the caller must invoke before it returns to user code."""
     dev = graph.device
+    if rng == "numpy" and graph.has_reachable_sink:
+        # a walk that reaches a sink consumes fewer uniforms: the layers are drawn one after the other, each from where the
+        # previous one left the stream (what consecutive batch_sample_neighbors calls do in the reference)
+        nd = torch.arange(nodes.start, nodes.stop, dtype=torch.int64, device=dev) if isinstance(nodes, range) else nodes
+        sn = None
+        if stream_nodes is not None:
+            a0 = stream_nodes[0]
+            sn = (torch.arange(a0.start, a0.stop, dtype=torch.int64, device=dev) if isinstance(a0, range) else a0, stream_nodes[1])
+        return [walk_sample(graph, nd, T, W, L, rng=rng, seed=seed, call=call + r, uniforms=None, stream_nodes=sn)
+                for r in range(layers)]
     as_range = nodes if isinstance(nodes, range) else None
     if as_range is not None:
         if as_range.step != 1 or as_range.start < 0 or as_range.stop > graph.V:
@@ -214,8 +279,6 @@ def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0,
     stride = 0
     with torch.cuda.device(dev):
         if rng == "numpy":
-            if graph.has_reachable_sink:
-                raise NotImplementedError("rng='numpy' needs a graph without reachable sinks; use rng='philox'")
             # stream offsets: a property of (graph, start nodes, W * L), not of the RNG state.  For a python range of
             # start nodes (what get_embeddings and item shards sample) they are computed once per graph and kept in
             # HBM, like the CSR itself; anything else runs ps_uniform_offsets per call.
@@ -281,9 +344,10 @@ def walk_paths(graph, starts, L, rng="numpy", seed=0, call=0, walk_mod=0):
     paths = torch.empty((B, L), dtype=torch.int32, device=dev)
     L_ = nv.lib()
     with torch.cuda.device(dev):
-        if rng == "numpy":
-            if graph.has_reachable_sink:
-                raise NotImplementedError("rng='numpy' needs a graph without reachable sinks; use rng='philox'")
+        if rng == "numpy" and graph.has_reachable_sink:
+            uniforms, uoff = _sink_stream(graph, st, 1, L)       # one walk per start node: W = 1
+            mode = nv.PS_RNG_STREAM
+        elif rng == "numpy":
             uoff = torch.empty(B, dtype=torch.int64, device=dev)
             total = torch.empty(1, dtype=torch.int64, device=dev)
             nv.call("ps_uniform_offsets", nv.ptr(graph.rowptr), nv.i64(graph.V), nv.ptr(st), nv.i64(B), nv.i32(1),

@@ -48,19 +48,95 @@ def test_golden_single_walk(golden):
         assert [int(v) for v in s._single_walk(int(st))] == ref.tolist()
 
 
-def test_sink_graph_numpy_mode_refuses_and_philox_matches_oracle(golden):
+def test_sink_graph_numpy_mode_matches_the_reference_and_philox_the_oracle(golden):
+    """A directed graph with a reachable sink: the reference's walk breaks there before drawing (utils/random_walk.py:65-69), so
+    its RNG consumption is data dependent.  rng='numpy' reproduces the reference's own output (golden G1 "S": ids, fp64 weights
+    and the np.random position afterwards) through per-walk stream positions found as a fixpoint (sampling.sink_walk_offsets);
+    rng='philox' is held to the oracle."""
     from oracle import c_oracle as co
     g = golden
     s = _sampler(g, "g1_S", 20, 3)
     assert s.graph.has_reachable_sink
-    with pytest.raises(NotImplementedError):
-        s.batch_sample_neighbors([0, 1, 2], 4)
+    np.random.seed(7)
+    nb, wt = s.batch_sample_neighbors([0, 1, 2, 3, 4], 4)
+    tail = np.random.random_sample()
+    for i in range(5):
+        k = int(g["g1_S_nvalid"][i])
+        assert [int(v) for v in nb[i]] == g["g1_S_ids"][i, :k].tolist() and len(nb[i]) == k
+        assert wt[i] == g["g1_S_weights"][i, :k].tolist()                 # fp64 bit-exact
+    assert tail == float(g["g1_S_tail"])                                  # the global stream advanced by the uniforms really consumed
+    # the same batch node by node (sample_neighbors) and walk by walk (_single_walk) consumes the stream identically
+    np.random.seed(7)
+    for i in range(5):
+        ids_i, w_i = s.sample_neighbors(i, 4)
+        k = int(g["g1_S_nvalid"][i])
+        assert [int(v) for v in ids_i] == g["g1_S_ids"][i, :k].tolist() and w_i == g["g1_S_weights"][i, :k].tolist()
+    assert np.random.random_sample() == float(g["g1_S_tail"])
+    cg = co.Graph(g["g1_S_edge_index"], g["g1_S_edge_weights"])
+    np.random.seed(3)
+    u = np.random.RandomState(3).random_sample(64)
+    pos = 0
+    for start in (0, 2, 4, 1, 3, 0):
+        ref, pos = co.single_walk(cg, start, 3, u, pos)
+        assert [int(v) for v in s._single_walk(start)] == ref
+    assert np.random.random_sample() == u[pos]
     s = _sampler(g, "g1_S", 20, 3, rng="philox", seed=99)
     b = s.sample_batch([0, 1, 2, 3, 4], 4)
-    cg = co.Graph(g["g1_S_edge_index"], g["g1_S_edge_weights"])
     ids, counts, nv, w, _, _ = co.walk_sample(cg, [0, 1, 2, 3, 4], 4, 3, 20, philox=(99, 0))
     assert np.array_equal(b.ids.cpu().numpy(), ids) and np.array_equal(b.counts.cpu().numpy(), counts)
     assert np.array_equal(b.nvalid.cpu().numpy(), nv)
+
+
+@pytest.mark.parametrize("L", [2, 3])
+def test_sink_graphs_numpy_mode_equals_the_sequential_oracle(L):
+    """Larger graphs with sinks against the C oracle's strictly sequential stream consumption (uoff = NULL: exact for any
+    graph): (a) a user -> item graph (every item is a sink: the number of steps is decided by the graph, two passes), (b) a
+    random directed graph in which a third of the nodes have no out-edges (the number of steps depends on the draws), (c) the
+    two-layer get_embeddings launch and an item shard of it.  ids, counts, fp64 weights and the stream position afterwards."""
+    from oracle import c_oracle as co
+    from pinsage_hip import sampling
+    from pinsage_hip.graph import DeviceGraph
+    rs = np.random.RandomState(4)
+    W, T = 30, 6
+    graphs = []
+    M, U, R = 300, 200, 6000
+    items, users = rs.randint(0, M, R), rs.randint(0, U, R) + M
+    graphs.append((np.stack([users, items]).astype(np.int64), (rs.randint(1, 11, R) * 0.5).astype(np.float32), M + U))
+    V, E = 400, 5000
+    src = rs.randint(0, V, E)
+    src = src[src % 3 != 0]                                             # nodes = 0 mod 3 never appear as a source: sinks
+    dst = rs.randint(0, V, src.size)
+    graphs.append((np.stack([src, dst]).astype(np.int64), (rs.random_sample(src.size) * 3 + 0.25).astype(np.float32), V))
+    for ei, ew, V_ in graphs:
+        g = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew))
+        assert g.has_reachable_sink
+        cg = co.Graph(ei, ew, num_nodes=g.V)
+        nodes = np.concatenate([np.arange(g.V), rs.randint(0, g.V, 100)])
+        u = np.random.RandomState(12).random_sample(nodes.size * W * L + 8)
+        ids, counts, nv, wts, used, _ = co.walk_sample(cg, nodes, T, L, W, uniforms=u)      # sequential consumption
+        assert 0 < used < nodes.size * W * L
+        np.random.seed(12)
+        b = sampling.walk_sample(g, nodes, T, W, L, rng="numpy")
+        assert np.random.random_sample() == u[used]
+        hi, hc, hn, hw = b.host()
+        assert np.array_equal(hi, ids) and np.array_equal(hc, counts) and np.array_equal(hn, nv)
+        valid = np.arange(T)[None, :] < nv[:, None]
+        assert np.array_equal(hw[valid], wts[valid])
+        # two consecutive calls (get_embeddings' per-layer samples) in one walk_sample_layers call, and a shard of them
+        nd = np.arange(min(g.V, 256))
+        u2 = np.random.RandomState(5).random_sample(2 * nd.size * W * L + 8)
+        r0 = co.walk_sample(cg, nd, T, L, W, uniforms=u2)
+        r1 = co.walk_sample(cg, nd, T, L, W, uniforms=u2[r0[4]:])
+        np.random.seed(5)
+        two = sampling.walk_sample_layers(g, range(nd.size), T, 2, W, L, rng="numpy")
+        assert np.random.random_sample() == u2[r0[4] + r1[4]]
+        for got, ref in zip(two, (r0, r1)):
+            assert np.array_equal(got.ids.cpu().numpy().astype(np.int64), ref[0]) and np.array_equal(got.counts.cpu().numpy(), ref[1])
+        np.random.seed(5)
+        part = sampling.walk_sample_layers(g, range(100, 180), T, 2, W, L, rng="numpy", stream_nodes=(range(nd.size), 100))
+        assert np.random.random_sample() == u2[r0[4] + r1[4]]
+        for got, ref in zip(part, (r0, r1)):
+            assert np.array_equal(got.ids.cpu().numpy().astype(np.int64), ref[0][100:180])
 
 
 @pytest.mark.parametrize("weights", ["half", "float", None])
@@ -335,10 +411,13 @@ def test_integration_md_ctypes_stub_reproduces_the_golden(golden):
 
 
 @pytest.mark.parametrize("W,L,T,layers", [(100, 2, 10, 2), (100, 2, 50, 3), (10, 3, 5, 2), (130, 1, 7, 4), (20, 2, 5, 11)])   # 11 layers: two launches
-def test_fused_layer_sampling_equals_separate_calls(W, L, T, layers):
+def test_fused_layer_sampling_equals_separate_calls(W, L, T, layers, monkeypatch):
     """ps_walk_sample_layers (all GCN layers' samples of a node in one wave; model/pinsage.py:271-275 draws them as
     consecutive batch_sample_neighbors calls) vs `layers` separate launches, in both RNG modes: ids, counts, nvalid
-    bit-identical, and in numpy mode the same final np.random state.  Isolated start nodes included."""
+    bit-identical, and in numpy mode the same final np.random state.  Isolated start nodes included.
+    PS_MT_POISON=1: the item shard's ranged stream buffer is filled with 0xFFFFFFFF before the generator writes its runs, so
+    a walk-kernel read outside the rank's runs cannot pass on stale same-seed words left in the allocator's block."""
+    monkeypatch.setenv("PS_MT_POISON", "1")
     from pinsage_hip.shard import HipOps
     from utils.random_walk import RandomWalkSampler
     ei, ew = bipartite_graph(2500, 1800, 120000, 5, "half")

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for bits in "$@"; do
   if [ "$bits" = "0" ]; then unset PS_HIP_LIB; else export PS_HIP_LIB=$GRAFT_REPO_ROOT/tools/ubench/_dbg/libps_dbg$bits.so; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_p$bits -o p -- python tools/bench_hamming.py 512 10000 59047 11 5 > gpurun_out/probe_$bits.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_p$bits -o p -- python tools/bench_hamming.py ${NBITS:-512} ${NQ:-10000} ${NITEMS:-59047} ${TOPK:-11} 5 > gpurun_out/probe_$bits.log 2>&1
   python - <<PY
 import csv
 out=[]
