@@ -168,7 +168,10 @@ def main():
     torch.cuda.synchronize()
     t_graph = time.time() - t0
     if big:
-        graph.wsorted = None                       # the sorted fp64 weights (16 GB here) are only kept for inspection
+        # 66 GB of graph + 64 GB of half bucket records + the 102 GB stand-in for the gathered hidden rows: while the job steps, the
+        # plain col / cdf / guide arrays (32 GB) and the sorted weights (16 GB) are dropped -- the walk kernel reads the same values
+        # from the packed blocks -- and restored (bit for bit) for the accounting and the CPU oracle afterwards
+        graph.compact()
         torch.cuda.empty_cache()
     sampler = RandomWalkSampler.from_graph(graph, walk_length=L, num_walks=W, rng=a.rng, seed=42)
     torch.manual_seed(2)
@@ -272,6 +275,15 @@ def main():
     value = items_per_step * a.steps / elapsed
     ksum = timer.summary()
 
+    gpu_ref = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        gpu_ref = parity_gpu_step(a, graph, pipe, sampler, step, M, T, W, L, LAYERS, big)
+    if big:
+        # the step's buffers (102 GB stand-in, activations) go, the plain graph arrays come back for the accounting / the oracle
+        emb = d_out = i_out = None
+        pipe.comm._bufs.clear()
+        torch.cuda.empty_cache()
+        graph.expand()
     out = None
     if rank == 0:
         # ---------------- roofline of every kernel (rank 0's shard), algorithmic bytes / flops ---------
@@ -427,7 +439,7 @@ def main():
             "roofline": roofline, "kernels": kern,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"], out["parity_check"] = cpu_baseline(a, graph, pipe, sampler, step, params, x_loc, A, M, T, W, L,
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline(a, graph, pipe, gpu_ref, params, x_loc, A, M, T, W, L,
                                                                     LAYERS, HID, D, nbits, nq, big)
             out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         if world == 1 and not big:            # config 5: 5 x 10^9 stream uniforms per shard pass -- Philox only
@@ -505,24 +517,8 @@ def oracle_samples(co, cg, nodes, T, W, L, layers, rng, seed, threads, call0=0):
     return out, rs
 
 
-def cpu_baseline(a, graph, pipe, sampler, step, params, x_loc, A, M, T, W, L, LAYERS, HID, D, nbits, nq, big=False):
-    """The CPU oracle (C port of the reference algorithm, pinned by the goldens) timed on this box's host cores on the
-    same workload -- the whole step when the catalogue fits (SYN-25M: every start item, both layers, the real pooled forward
-    over the real hidden rows, all queries), otherwise a bounded sample -- with torch CPU for the dense layers (what the
-    reference runs).  The oracle's outputs are then COMPARED with the GPU's (`parity_check`): one more GPU step is run from a
-    known RNG state (np.random.seed(42) / Philox call 0) and its sampled neighbour ids / visit counts, embeddings, LSH codes
-    and top-k (distance, id) lists are held to the oracle's -- bit-exact for ids / counts / codes / top-k, 1e-5 for the
-    fp32 embeddings (north_star's tolerances).
-    Config 5: the sample is 65 536 start items of the shard and 256 queries over the shard's codes (the CSR + CDF, 25 GB,
-    are copied to the host for the oracle), scaled to the shard; embeddings cannot be compared there (the gathered rows of
-    the other seven ranks are stand-ins)."""
-    from oracle import c_oracle as co
-    from pinsage_hip import sampling
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(threads, co.max_threads()))
-    torch.set_num_threads(threads)
-    dev = x_loc.device
-    cg = co.Graph.from_arrays(graph.rowptr.cpu().numpy(), graph.col.cpu().numpy(), graph.cdf.cpu().numpy())
+def cpu_sample_nodes(a, pipe, M, big):
+    """the start items the CPU leg runs: the whole catalogue when it fits, otherwise a uniform sample of the shard"""
     n_items = pipe.hi - pipe.lo if big else M                 # what one step embeds
     if big and a.cpu_sample <= 0:
         a.cpu_sample = 65536
@@ -530,7 +526,14 @@ def cpu_baseline(a, graph, pipe, sampler, step, params, x_loc, A, M, T, W, L, LA
     whole = (S == n_items) and not big
     rs = np.random.RandomState(0)
     nodes = np.sort(rs.choice(n_items, size=S, replace=False)) + (pipe.lo if big else 0)
-    # ---- the GPU step the oracle is compared with: known RNG state, outside every timed region ----
+    return n_items, S, whole, nodes
+
+
+def parity_gpu_step(a, graph, pipe, sampler, step, M, T, W, L, LAYERS, big):
+    """The GPU step the oracle is compared with: one more step from a known RNG state (np.random.seed(42) / Philox call 0),
+    outside every timed region, and the sampler's output for the same state."""
+    from pinsage_hip import sampling
+    n_items, S, whole, nodes = cpu_sample_nodes(a, pipe, M, big)
     with torch.no_grad():
         sampler._calls = 0
         emb_g, d_g, i_g = step()
@@ -542,9 +545,31 @@ def cpu_baseline(a, graph, pipe, sampler, step, params, x_loc, A, M, T, W, L, LA
         if whole:
             got = sampler.sample_batches(range(pipe.lo, pipe.hi), T, LAYERS)
         else:                                                  # config 5 / --cpu-sample: the sampled start nodes only (Philox)
-            nd = torch.from_numpy(nodes).to(dev)
+            nd = torch.from_numpy(nodes).to(emb_g.device)
             got = [sampling.walk_sample(graph, nd, T, W, L, rng="philox", seed=42, call=c) for c in range(LAYERS)]
         torch.cuda.synchronize()
+    return {"emb": emb_g, "d": d_g, "i": i_g, "tail": tail_g, "codes": codes_g, "got": got}
+
+
+def cpu_baseline(a, graph, pipe, gpu_ref, params, x_loc, A, M, T, W, L, LAYERS, HID, D, nbits, nq, big=False):
+    """The CPU oracle (C port of the reference algorithm, pinned by the goldens) timed on this box's host cores on the
+    same workload -- the whole step when the catalogue fits (SYN-25M: every start item, both layers, the real pooled forward
+    over the real hidden rows, all queries), otherwise a bounded sample -- with torch CPU for the dense layers (what the
+    reference runs).  The oracle's outputs are then COMPARED with the GPU's (`parity_check`): one more GPU step is run from a
+    known RNG state (np.random.seed(42) / Philox call 0) and its sampled neighbour ids / visit counts, embeddings, LSH codes
+    and top-k (distance, id) lists are held to the oracle's -- bit-exact for ids / counts / codes / top-k, 1e-5 for the
+    fp32 embeddings (north_star's tolerances).
+    Config 5: the sample is 65 536 start items of the shard and 256 queries over the shard's codes (the CSR + CDF, 25 GB,
+    are copied to the host for the oracle), scaled to the shard; embeddings cannot be compared there (the gathered rows of
+    the other seven ranks are stand-ins)."""
+    from oracle import c_oracle as co
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(threads, co.max_threads()))
+    torch.set_num_threads(threads)
+    dev = x_loc.device
+    cg = co.Graph.from_arrays(graph.rowptr.cpu().numpy(), graph.col.cpu().numpy(), graph.cdf.cpu().numpy())
+    n_items, S, whole, nodes = cpu_sample_nodes(a, pipe, M, big)
+    emb_g, d_g, i_g, tail_g, codes_g, got = (gpu_ref[k] for k in ("emb", "d", "i", "tail", "codes", "got"))
     # ---- timed: sampler ----
     rng_cpu = a.rng if whole else "philox"
     t0 = time.perf_counter()

@@ -46,6 +46,9 @@ extern "C" {
                                walk that stops early consumes fewer than L uniforms (utils/random_walk.py:65-69) and the positions
                                are the running count of uniforms consumed by every earlier walk (host: sampling.sink_walk_offsets) */
 
+#define PS_WALK_HALF_BUCKETS 0x100 /* OR-ed into rng_mode of ps_walk_sample / ps_walk_sample_layers: `buckets` holds the 32-byte half
+                                      records of ps_bucket_build_half instead of the 64-byte records of ps_bucket_build */
+
 typedef void *ps_stream_t;
 
 int ps_abi_version(void);
@@ -88,6 +91,16 @@ int ps_pack_edges(const int32_t *col, const double *cdf, const int32_t *guide, i
 int ps_bucket_build(const int64_t *rowptr, const int32_t *col, const double *cdf, const int32_t *guide, int64_t V,
                     int64_t E, void *buckets, ps_stream_t stream);
 
+/* The same table at half the size for graphs whose 64-byte records do not fit (BASELINE config 5: 2 x 10^9 edges = 64 GB instead of
+ * 128): record lo[v] + j = [lo32(cdf[g]) .. lo32(cdf[g+3]) | col[g] .. col[g+3]] with g the bucket's guide position and lo32 = the
+ * fp64 value rounded DOWN to fp32 (cdf lies in [lo32, next float): u < lo32 proves u < cdf, u >= the next float proves u >= cdf);
+ * positions past the row end as in ps_bucket_build (2.0f / the row's last destination).  A step is answered from its 32-byte
+ * record when these bounds prove one of the four candidates to be the searchsorted pick; a u inside a rounding sliver, or beyond
+ * the fourth candidate, makes the walk kernel repeat the search through the packed blocks.  Same results bit for bit.
+ * buckets: 32 * E bytes, 64-B aligned; pass PS_WALK_HALF_BUCKETS with the RNG mode. */
+int ps_bucket_build_half(const int64_t *rowptr, const int32_t *col, const double *cdf, const int32_t *guide, int64_t V,
+                         int64_t E, void *buckets, ps_stream_t stream);
+
 /* flags[0] = 1 iff some edge points at a node with out-degree 0 (a reachable sink: the
  * reference's walk then breaks early, utils/random_walk.py:68-69, and its RNG consumption
  * becomes data dependent); flags[1] = max out-degree.  flags int64[2]. */
@@ -106,7 +119,9 @@ int ps_graph_stats(const int64_t *rowptr, const int32_t *col, int64_t E, int64_t
  * nodeinfo/guide (both or neither; from ps_guide_build) select the bucket-table lookup; NULL = plain
  * binary search over the CDF row.  packed (from ps_pack_edges; needs nodeinfo) reads cdf/col/guide from
  * the interleaved 128-byte blocks instead of the three arrays; start rows of up to ~40 blocks are searched in LDS.
- * buckets (from ps_bucket_build; needs nodeinfo) answers every other step from one 64-byte record. */
+ * With packed, col / cdf / guide may be NULL (the blocks hold the same values: graphs that fill the GPU drop the plain arrays).
+ * buckets (from ps_bucket_build; needs nodeinfo) answers every other step from one 64-byte record; with PS_WALK_HALF_BUCKETS
+ * OR-ed into rng_mode it is the 32-byte form of ps_bucket_build_half. */
 int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                    const int64_t *starts, int64_t B, int W, int L, int T,
                    int rng_mode, const double *uniforms, const int64_t *uoff,

@@ -221,6 +221,40 @@ __global__ __launch_bounds__(256) void bucket_build_kernel(const int64_t *rowptr
     }
 }
 
+// 32-byte half records (see ps_bucket_build_half in pinsage_hip.h): [c0 c1 c2 c3 | k0 k1 k2 k3] = the four CDF entries from the
+// bucket's guide position on, each ROUNDED DOWN to fp32, and their destinations.  With lo = (double)c_i and hi = the next float
+// above it, cdf_i lies in [lo, hi): `u < lo` proves `u < cdf_i` and `u >= hi` proves `u >= cdf_i`, so the walk takes k_i when
+// u >= hi_{i-1} and u < lo_i -- exactly the searchsorted answer -- and repeats the search through the packed blocks in the sliver
+// in between (2^-24 of the value: ~10^-5 of a bucket for a row of 100 edges) or when the answer lies beyond the fourth candidate.
+__device__ __forceinline__ float round_down_f32(double c) {
+    float f = (float)c;                                       // round to nearest, then step down if that went up
+    if ((double)f > c) f = __uint_as_float(__float_as_uint(f) - 1u);     // c > 0: positive floats order like their bits
+    return f;
+}
+__global__ __launch_bounds__(256) void bucket_half_build_kernel(const int64_t *rowptr, const int32_t *col, const double *cdf,
+                                                                const int32_t *guide, int64_t V, unsigned char *buckets) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t v = wave; v < V; v += nwaves) {
+        const int64_t lo = rowptr[v], hi = rowptr[v + 1];
+        for (int64_t e = lo + lane; e < hi; e += 64) {
+            const int64_t first = lo + guide[e];
+            float c[4];
+            int32_t k[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t idx = first + i;
+                c[i] = idx < hi ? round_down_f32(cdf[idx]) : 2.0f;  // past the row end: always "> u", destination = last edge
+                k[i] = col[idx < hi ? idx : hi - 1];
+            }
+            unsigned char *r = buckets + (size_t)e * 32;
+            reinterpret_cast<float4 *>(r)[0] = make_float4(c[0], c[1], c[2], c[3]);
+            reinterpret_cast<int4 *>(r)[1] = make_int4(k[0], k[1], k[2], k[3]);
+        }
+    }
+}
+
 int radix_bits(int64_t V) {
     int bits = 1;
     while (((int64_t)1 << bits) < V && bits < 32) ++bits;
@@ -294,6 +328,19 @@ extern "C" int ps_bucket_build(const int64_t *rowptr, const int32_t *col, const 
     int64_t g = ps_cdiv(V, 4);
     if (g > 256 * 32) g = 256 * 32;
     hipLaunchKernelGGL(bucket_build_kernel, dim3((unsigned)g), dim3(256), 0, ps_stream(stream), rowptr, col, cdf, guide, V,
+                       reinterpret_cast<unsigned char *>(buckets));
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+extern "C" int ps_bucket_build_half(const int64_t *rowptr, const int32_t *col, const double *cdf, const int32_t *guide,
+                                    int64_t V, int64_t E, void *buckets, ps_stream_t stream) {
+    if (V < 0 || E < 0) return PS_EINVAL;
+    if (V == 0 || E == 0) return PS_OK;
+    if (!rowptr || !col || !cdf || !guide || !buckets || reinterpret_cast<size_t>(buckets) % 64 != 0) return PS_EINVAL;
+    int64_t g = ps_cdiv(V, 4);
+    if (g > 256 * 32) g = 256 * 32;
+    hipLaunchKernelGGL(bucket_half_build_kernel, dim3((unsigned)g), dim3(256), 0, ps_stream(stream), rowptr, col, cdf, guide, V,
                        reinterpret_cast<unsigned char *>(buckets));
     PS_CHECK_LAUNCH();
     return PS_OK;

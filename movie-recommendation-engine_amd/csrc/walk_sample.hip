@@ -38,7 +38,8 @@ struct WalkArgs {
     int hs_log2;
     int stage_blocks;   // start rows of at most this many 128-byte blocks are searched in LDS
     int region_words;   // LDS words shared by the staged row (walk phase) and the hash table (count phase)
-    const unsigned char *buckets;   // 64-byte bucket records (ps_bucket_build) or NULL
+    const unsigned char *buckets;   // 64-byte bucket records (ps_bucket_build), 32-byte half records (ps_bucket_build_half) or NULL
+    int half_buckets;               // 1: `buckets` holds the 32-byte form (PS_WALK_HALF_BUCKETS)
     int bitmap_words;               // LDS words of the count-class bitmap: W * L / 32 + 1, padded
     int rounds;                     // independent samples per start node (one per GCN layer), all in one wave
     int64_t round_stride;           // PS_RNG_STREAM: uniforms of round r start at r * round_stride + uoff[i]
@@ -289,6 +290,55 @@ __device__ __forceinline__ void search_two_buckets(const unsigned char *buckets,
     }
 }
 
+// 32-byte half records (graphs whose 64-byte records would not fit, BASELINE config 5: 64 GB instead of 128 at 2 x 10^9 edges):
+// [c0 c1 c2 c3 | k0 k1 k2 k3] = four candidates' CDF entries rounded DOWN to fp32 and their destinations.  cdf_i lies in
+// [lo_i, hi_i) with lo_i = (double)c_i, hi_i = the next float: the first i with u < hi_i is the pick if also u < lo_i (then
+// cdf_{i-1} <= u < cdf_i is proven); a u inside a sliver [lo_i, hi_i), or beyond the fourth candidate, repeats the search the long
+// way.  Two 16-byte loads from one half of a 64-byte sector.
+__device__ __forceinline__ int32_t half_pick(const float4 &c, const int4 &k, double u) {
+    const double l0 = (double)c.x, l1 = (double)c.y, l2 = (double)c.z, l3 = (double)c.w;
+    const double h0 = (double)__uint_as_float(__float_as_uint(c.x) + 1u), h1 = (double)__uint_as_float(__float_as_uint(c.y) + 1u);
+    const double h2 = (double)__uint_as_float(__float_as_uint(c.z) + 1u), h3 = (double)__uint_as_float(__float_as_uint(c.w) + 1u);
+    if (u < h0) return u < l0 ? k.x : -1;
+    if (u < h1) return u < l1 ? k.y : -1;
+    if (u < h2) return u < l2 ? k.z : -1;
+    if (u < h3) return u < l3 ? k.w : -1;
+    return -1;
+}
+template <class Acc>
+__device__ __forceinline__ void search_two_half(const unsigned char *buckets, const Acc &acc, bool aliveA, eidx_t loA, eidx_t hiA,
+                                                double uA, bool aliveB, eidx_t loB, eidx_t hiB, double uB, int32_t &nA, int32_t &nB) {
+    nA = -1;
+    nB = -1;
+    float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
+    int4 kA = make_int4(-1, -1, -1, -1), kB = kA;
+    if (aliveA) {
+        const uint32_t deg = (uint32_t)(hiA - loA);
+        uint32_t j = (uint32_t)(uA * (double)deg);
+        if (j >= deg) j = deg - 1;
+        const unsigned char *r = buckets + (size_t)(loA + j) * 32;
+        cA = reinterpret_cast<const float4 *>(r)[0];
+        kA = reinterpret_cast<const int4 *>(r)[1];
+    }
+    if (aliveB) {
+        const uint32_t deg = (uint32_t)(hiB - loB);
+        uint32_t j = (uint32_t)(uB * (double)deg);
+        if (j >= deg) j = deg - 1;
+        const unsigned char *r = buckets + (size_t)(loB + j) * 32;
+        cB = reinterpret_cast<const float4 *>(r)[0];
+        kB = reinterpret_cast<const int4 *>(r)[1];
+    }
+    if (aliveA) nA = half_pick(cA, kA, uA);
+    if (aliveB) nB = half_pick(cB, kB, uB);
+    const bool moreA = aliveA && nA < 0, moreB = aliveB && nB < 0;
+    if (__ballot(moreA || moreB) != 0ull) {                      // the long way for what is left
+        int32_t fA = -1, fB = -1;
+        search_two(acc, moreA, loA, hiA, uA, moreB, loB, hiB, uB, fA, fB);
+        if (moreA) nA = fA;
+        if (moreB) nB = fB;
+    }
+}
+
 // Start state of searchsorted(cdf[lo:hi], u, 'right'): with a guide table the search starts at the bucket
 // floor(u * deg) (guide = #{cdf <= (j-1)/deg} <= answer) and first scans forward; `n` counts probes.
 __device__ __forceinline__ void search_init(const int32_t *guide, const unsigned char *packed, eidx_t lo, eidx_t hi,
@@ -429,6 +479,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                 if ((PS_WS_DEBUG & 2) && st > 0) { aliveA = false; aliveB = false; }
                 if ((PS_WS_DEBUG & 1) && st == 0) { nA = grow.k(lo0 + (eidx_t)((uint32_t)lane % (uint32_t)(hi0 - lo0))); nB = nA; }
                 else if (staged && st == 0) search_two(lrow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
+                else if (a.buckets && a.half_buckets) search_two_half(a.buckets, grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
                 else if (a.buckets) search_two_buckets(a.buckets, grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
                 else search_two(grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
                 if (aliveA) curA = nA;
@@ -636,14 +687,17 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
                               const uint32_t *nodeinfo, const int32_t *guide, const void *packed, const void *buckets,
                               int rounds, int64_t round_stride, int32_t *ids, int32_t *counts, int32_t *nvalid,
                               ps_stream_t stream) {
+    const int half_buckets = (rng_mode & PS_WALK_HALF_BUCKETS) ? 1 : 0;      // a flag beside the RNG mode: `buckets` is the 32-byte form
+    rng_mode &= ~PS_WALK_HALF_BUCKETS;
     if (B < 0 || W <= 0 || L <= 0 || T <= 0 || V < 0 || rounds <= 0 || rounds > 8 || round_stride < 0) return PS_EINVAL;
     if (B == 0) return PS_OK;
-    if (!rowptr || !col || !cdf || !starts || !ids || !counts || !nvalid) return PS_EINVAL;
+    if (!rowptr || !starts || !ids || !counts || !nvalid) return PS_EINVAL;
+    if (!packed && (!col || !cdf)) return PS_EINVAL;           // the packed blocks hold the same values: col / cdf / guide may then be NULL
     if (rng_mode != PS_RNG_STREAM && rng_mode != PS_RNG_PHILOX && rng_mode != PS_RNG_STREAM_RAW && rng_mode != PS_RNG_STREAM_WALKS)
         return PS_EINVAL;
     if (rng_mode != PS_RNG_PHILOX && (!uniforms || !uoff)) return PS_EINVAL;
     if (rng_mode == PS_RNG_STREAM_WALKS && rounds != 1) return PS_EUNSUPPORTED;    // per-walk positions: one sample per launch
-    if ((nodeinfo == nullptr) != (guide == nullptr)) return PS_EINVAL;
+    if (!packed && (nodeinfo == nullptr) != (guide == nullptr)) return PS_EINVAL;
     if (packed && !nodeinfo) return PS_EINVAL;
     if (buckets && (!nodeinfo || reinterpret_cast<size_t>(buckets) % 64 != 0)) return PS_EINVAL;
     const int64_t P = (int64_t)W * L;
@@ -653,7 +707,7 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
     int hs_log2 = 6;
     while ((1 << hs_log2) * 4 < 5 * P) ++hs_log2;      // table >= 1.25 P slots (load factor <= 0.8)
     WalkArgs a{rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff,
-               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0, reinterpret_cast<const unsigned char *>(buckets), 0,
+               (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0, reinterpret_cast<const unsigned char *>(buckets), half_buckets, 0,
                rounds, round_stride};
     // LDS budget: the kernel holds 24 waves per CU by registers; 160 KB / 24 leaves ~6.6 KB per wave, and whatever
     // the position buffers and the hash table do not need of that lets longer start rows be staged.

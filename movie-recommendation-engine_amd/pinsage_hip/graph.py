@@ -56,13 +56,25 @@ class DeviceGraph:
             if E:
                 nv.call("ps_pack_edges", nv.ptr(self.col), nv.ptr(self.cdf), nv.ptr(self.guide), nv.i64(E),
                         nv.ptr(self.packed), nv.stream())
-            # 64-byte bucket records (one sector per walk step); skipped when they would not fit comfortably
-            self.buckets = None
+            # bucket records (one sector per later walk step): the 64-byte form when it fits comfortably (4 x the adjacency:
+            # SYN-25M 3.2 GB), the 32-byte half records when only they do (BASELINE config 5: 64 GB beside the 66 GB graph),
+            # nothing otherwise.  buckets = True / "full", "half", False force a form.  The CSR build's sort workspace is
+            # returned first: at 2 x 10^9 edges it is the size of the half records.
+            del ws
+            self.buckets, self.bucket_bytes = None, 0
             if E and buckets is not False:
+                torch.cuda.empty_cache()
                 free = torch.cuda.mem_get_info(dev)[0]
-                if buckets is True or E * 64 < free // 2:
-                    self.buckets = torch.empty(E * 64, dtype=torch.uint8, device=dev)
+                form = {True: "full", "full": "full", "half": "half", None: None}[buckets]
+                if form is None:
+                    form = "full" if E * 64 < free // 2 else ("half" if E * 32 < (free * 3) // 5 else None)
+                if form == "full":
+                    self.buckets, self.bucket_bytes = torch.empty(E * 64, dtype=torch.uint8, device=dev), 64
                     nv.call("ps_bucket_build", nv.ptr(self.rowptr), nv.ptr(self.col), nv.ptr(self.cdf), nv.ptr(self.guide),
+                            nv.i64(V), nv.i64(E), nv.ptr(self.buckets), nv.stream())
+                elif form == "half":
+                    self.buckets, self.bucket_bytes = torch.empty(E * 32, dtype=torch.uint8, device=dev), 32
+                    nv.call("ps_bucket_build_half", nv.ptr(self.rowptr), nv.ptr(self.col), nv.ptr(self.cdf), nv.ptr(self.guide),
                             nv.i64(V), nv.i64(E), nv.ptr(self.buckets), nv.stream())
             flags = torch.zeros(2, dtype=torch.int64, device=dev)
             nv.call("ps_graph_stats", nv.ptr(self.rowptr), nv.ptr(self.col), nv.i64(E), nv.i64(V), nv.ptr(flags),
@@ -71,7 +83,32 @@ class DeviceGraph:
         self.has_reachable_sink = bool(f[0])
         self.max_degree = int(f[1])
         self.wsorted = wsorted
-        del ws
+
+    def compact(self):
+        """Drop the plain `col` / `cdf` / `guide` arrays (16 bytes per edge): the walk kernels read the same values from the
+        interleaved 128-byte blocks of `packed` (+ `nodeinfo`, `buckets`), which stay.  For graphs that fill the GPU (BASELINE
+        config 5: 32 of 162 GB); `expand()` restores them bit for bit.  ps_walk_paths and host-side inspection need the plain
+        arrays."""
+        if self.packed is None or self.E == 0:
+            return self
+        self.col = self.cdf = self.guide = None
+        self.wsorted = None
+        return self
+
+    def expand(self):
+        """Rebuild `col` / `cdf` / `guide` from the packed blocks (exact copies: the blocks hold the same bits)."""
+        if self.col is not None or self.E == 0:
+            return self
+        blk = self.packed.view(-1, 128)
+        self.cdf = blk[:, :64].contiguous().view(torch.float64).reshape(-1)[: self.E].contiguous()
+        self.col = blk[:, 64:96].contiguous().view(torch.int32).reshape(-1)[: self.E].contiguous()
+        self.guide = blk[:, 96:128].contiguous().view(torch.int32).reshape(-1)[: self.E].contiguous()
+        return self
+
+    @property
+    def walk_flags(self):
+        """flags OR-ed into rng_mode of the walk launches (the form of `buckets`)"""
+        return nv.PS_WALK_HALF_BUCKETS if self.bucket_bytes == 32 else 0
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.cdf, self.nodeinfo, self.guide, self.packed,

@@ -236,7 +236,8 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
         else:
             raise ValueError("rng must be 'numpy' or 'philox'")
         nv.call("ps_walk_sample", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
-                                   nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T), nv.i32(mode),
+                                   nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T),
+                                   nv.i32(mode | (graph.walk_flags if (use_guide and use_buckets) else 0)),
                                    nv.ptr(uniforms), nv.ptr(uoff), nv.u64(seed & (2 ** 64 - 1)), nv.u32(call),
                                    nv.ptr(graph.nodeinfo) if use_guide else nv.ptr(None),
                                    nv.ptr(graph.guide) if use_guide else nv.ptr(None),
@@ -329,7 +330,7 @@ def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0,
             if uniforms is not None and r0:
                 u = uniforms[2 * r0 * stride:] if mode == nv.PS_RNG_STREAM_RAW else uniforms[r0 * stride:]
             nv.call("ps_walk_sample_layers", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
-                    nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T), nv.i32(mode), nv.ptr(u), nv.ptr(uoff),
+                    nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T), nv.i32(mode | graph.walk_flags), nv.ptr(u), nv.ptr(uoff),
                     nv.i64(stride), nv.u64(seed & (2 ** 64 - 1)), nv.u32(call + r0), nv.ptr(graph.nodeinfo), nv.ptr(graph.guide),
                     nv.ptr(graph.packed), nv.ptr(getattr(graph, "buckets", None)), nv.i32(n), nv.ptr(ids[r0:r0 + n]),
                     nv.ptr(counts[r0:r0 + n]), nv.ptr(nvalid[r0:r0 + n]), nv.stream())

@@ -313,7 +313,26 @@ def test_config5_shaped_graph_without_bucket_records():
     b1 = sampling.walk_sample(gb, nodes, 10, 100, 2, rng="philox", seed=42, call=1)
     assert torch.equal(a.ids, b.ids) and torch.equal(a.counts, b.counts) and torch.equal(a.nvalid, b.nvalid)
     assert torch.equal(two[1].ids, b1.ids) and torch.equal(two[1].counts, b1.counts)
+    # the 32-byte half records config 5 itself uses (64 GB at 2 x 10^9 edges): same rows again, one launch and fused layers
+    del gb
+    torch.cuda.empty_cache()
+    gh = DeviceGraph(ei, ew, buckets="half")
+    assert gh.bucket_bytes == 32
+    h = sampling.walk_sample(gh, nodes, 10, 100, 2, rng="philox", seed=42, call=0)
+    h2 = sampling.walk_sample_layers(gh, nodes, 10, 2, 100, 2, rng="philox", seed=42, call=0)
+    assert torch.equal(a.ids, h.ids) and torch.equal(a.counts, h.counts) and torch.equal(a.nvalid, h.nvalid)
+    assert torch.equal(h2[1].ids, b1.ids) and torch.equal(h2[1].counts, b1.counts)
     # items of this graph may be unrated (isolated): they return the empty result on both paths
+    # the graph as config 5 keeps it while it steps: plain col / cdf / guide dropped (the packed blocks hold the same values), then
+    # restored bit for bit
+    col0, cdf0, guide0 = gh.col.clone(), gh.cdf.clone(), gh.guide.clone()
+    gh.compact()
+    assert gh.col is None and gh.cdf is None and gh.guide is None
+    hc = sampling.walk_sample(gh, nodes, 10, 100, 2, rng="philox", seed=42, call=0)
+    assert torch.equal(a.ids, hc.ids) and torch.equal(a.counts, hc.counts)
+    gh.expand()
+    assert torch.equal(gh.col, col0) and torch.equal(gh.cdf, cdf0) and torch.equal(gh.guide, guide0)
+    gb = gh
     iso = (gb.rowptr[nodes + 1] - gb.rowptr[nodes]) == 0
     assert bool((a.nvalid[iso] == 0).all()) and bool((a.nvalid[~iso] > 0).all())
 
@@ -386,8 +405,8 @@ def test_device_ingest_full_size_equals_host_factorize():
 
 def test_config5_full_scale_shard_sampling_and_oracle_parity():
     """BASELINE config 5 at its real size, as one of its eight ranks sees it: the replicated graph of 100 M items, 10 M users
-    and 10^9 ratings (2 x 10^9 directed edges, 66 GB resident without the 128 GB of bucket records, so every step takes the
-    packed-block search), Philox uniforms, item shards of 12.5 M.  Every shard of the catalogue is sampled (both GCN layers
+    and 10^9 ratings (2 x 10^9 directed edges: 66 GB + the 64 GB of 32-byte half bucket records, since the 128 GB of full
+    records do not fit), Philox uniforms, item shards of 12.5 M.  Every shard of the catalogue is sampled (both GCN layers
     in one launch) and held to the size-independent properties; the C oracle then replays ~1 100 start nodes -- the
     maximum-degree item rows (1.4 M edges: 21-probe searches), the maximum-degree user rows and random items of every shard
     -- on a host copy of the CSR + CDF, and the pinned python oracle rebuilds the CDF of the heaviest rows from their
@@ -407,12 +426,12 @@ def test_config5_full_scale_shard_sampling_and_oracle_parity():
     T, W, L = 10, 100, 2
     t0 = time.time()
     ei, ew = synth.bipartite_ratings(U, M, R, seed=20240601, device=dev)
-    g = DeviceGraph(ei, ew, buckets=False)
+    g = DeviceGraph(ei, ew)                                # 128 GB of 64-byte records do not fit: the 32-byte half records (64 GB)
     del ei, ew
     torch.cuda.empty_cache()
-    print(f"config 5 graph: V={g.V} E={g.E} max degree {g.max_degree}, {g.nbytes() / 1e9:.1f} GB resident, "
-          f"built in {time.time() - t0:.1f} s", flush=True)
-    assert g.V == M + U and g.E == 2 * R and g.buckets is None and not g.has_reachable_sink
+    print(f"config 5 graph: V={g.V} E={g.E} max degree {g.max_degree}, {g.nbytes() / 1e9:.1f} GB resident "
+          f"({g.bucket_bytes}-byte bucket records), built in {time.time() - t0:.1f} s", flush=True)
+    assert g.V == M + U and g.E == 2 * R and g.bucket_bytes == 32 and not g.has_reachable_sink
     deg = g.rowptr[1:] - g.rowptr[:-1]
     assert int(deg[:M].min()) >= 1 and g.max_degree == int(deg.max()) > 1_000_000
     chunk = M // P

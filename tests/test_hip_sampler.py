@@ -252,9 +252,12 @@ def test_guide_table_is_exact_on_skewed_weights():
     c = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=True, use_packed=False)
     d = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=True, use_buckets=False)
     e = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_packed=False, use_buckets=False)
-    assert g.buckets is not None                              # a: LDS-staged start rows + bucket records
+    assert g.buckets is not None and g.bucket_bytes == 64    # a: LDS-staged start rows + bucket records
+    gh = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew), buckets="half")     # 32-byte half records (config 5's form)
+    assert gh.bucket_bytes == 32 and gh.buckets.numel() == 32 * gh.E
+    f = sampling.walk_sample(gh, nodes, 20, 100, 3, rng="philox", seed=5)
     ids, counts, nv, _, _, _ = co.walk_sample(cg, nodes, 20, 3, 100, philox=(5, 0), threads=8)
-    for x in (a, b, c, d, e):
+    for x in (a, b, c, d, e, f):
         assert np.array_equal(x.ids.cpu().numpy(), ids) and np.array_equal(x.counts.cpu().numpy(), counts)
         assert np.array_equal(x.nvalid.cpu().numpy(), nv)
 
@@ -382,6 +385,54 @@ def test_bucket_records_match_their_definition():
                     assert cs[e, i] == cdf[idx] and ks[e, i] == col[idx]
                 else:
                     assert cs[e, i] == 2.0 and ks[e, i] == col[hi - 1]
+
+
+def test_half_bucket_records_match_their_definition_and_the_full_records():
+    """ps_bucket_build_half: record lo+j = [fp32 lower bounds of cdf[g] .. cdf[g+3] | col[g] .. col[g+3]] with g the bucket's guide
+    position (past the row end: 2.0 / the row's last destination); every fp32 field is the nearest float at or below its fp64
+    value.  Walks through half records == walks through full records == plain arrays, in both RNG modes and for fused layers,
+    on rating weights and on weights that put many CDF entries into one bucket."""
+    from pinsage_hip import sampling
+    from pinsage_hip.graph import DeviceGraph
+    rs = np.random.RandomState(8)
+    for weights in ("half", "skew"):
+        ei, ew = bipartite_graph(600, 500, 40000, 3, "half")
+        if weights == "skew":
+            n = ei.shape[1] // 2
+            w = np.exp(rs.uniform(np.log(1e-3), np.log(1e4), size=n)).astype(np.float32)
+            ew = np.concatenate([w, w])
+        gf = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew), buckets="full")
+        g = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew), buckets="half")
+        rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+        cdf, guide = g.cdf.cpu().numpy(), g.guide.cpu().numpy()
+        raw = g.buckets.cpu().numpy().reshape(g.E, 32)
+        c = raw[:, :16].copy().view(np.float32)
+        k = raw[:, 16:32].copy().view(np.int32)
+        lo_of = np.repeat(rowptr[:-1], np.diff(rowptr))
+        hi_of = np.repeat(rowptr[1:], np.diff(rowptr))
+        first = lo_of + guide
+        for i in range(4):
+            idx = first + i
+            inside = idx < hi_of
+            want_c = np.where(inside, cdf[np.minimum(idx, g.E - 1)], 2.0)
+            want_k = col[np.where(inside, idx, hi_of - 1)]
+            assert np.array_equal(k[:, i], want_k)
+            assert bool((c[:, i].astype(np.float64) <= want_c).all())
+            assert bool((np.nextafter(c[:, i], np.float32(np.inf)).astype(np.float64) > want_c).all())
+        nodes = np.arange(g.V)
+        for rng in ("philox", "numpy"):
+            np.random.seed(2)
+            a = sampling.walk_sample(gf, nodes, 10, 100, 2, rng=rng, seed=4, call=1)
+            np.random.seed(2)
+            b = sampling.walk_sample(g, nodes, 10, 100, 2, rng=rng, seed=4, call=1)
+            np.random.seed(2)
+            c_ = sampling.walk_sample(g, nodes, 10, 100, 2, rng=rng, seed=4, call=1, use_guide=False)
+            for x in (b, c_):
+                assert torch.equal(x.ids, a.ids) and torch.equal(x.counts, a.counts) and torch.equal(x.nvalid, a.nvalid)
+        two_f = sampling.walk_sample_layers(gf, range(600), 10, 2, 100, 2, rng="philox", seed=4, call=0)
+        two_h = sampling.walk_sample_layers(g, range(600), 10, 2, 100, 2, rng="philox", seed=4, call=0)
+        for x, y in zip(two_f, two_h):
+            assert torch.equal(x.ids, y.ids) and torch.equal(x.counts, y.counts)
 
 
 def test_integration_md_ctypes_stub_reproduces_the_golden(golden):
