@@ -43,6 +43,7 @@
 // matrix work halves (65 us) but the per-tile parts do not (usual exit 18 us, hit path 70 us): that pass is bound by the
 // epilogue, not by the matrix pipe.
 #include "ps_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -65,6 +66,16 @@ extern "C" int ps_debug_hm_counts(unsigned long long *host, int reset) {
 }
 #else
 #define PS_HM_COUNT(slot, n) do {} while (0)
+#endif
+#if PS_HM_DEBUG & 512     // per-workgroup start / end stamps of the pipelined collect pass (tools/hm_times.py): load balance
+__device__ unsigned long long ps_hm_times[4 * 4096];
+extern "C" int ps_debug_hm_times_clear() {
+    static unsigned long long z[4 * 4096];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(ps_hm_times), z, sizeof(z));
+}
+extern "C" int ps_debug_hm_times(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ps_hm_times), sizeof(unsigned long long) * 4 * 4096);
+}
 #endif
 constexpr uint32_t EMPTY_KEY = 0xffffffffu;
 constexpr int NBUF = 4;                    // ring entries: one being multiplied (from registers), one being read into registers, two in flight
@@ -481,6 +492,452 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
     }
 }
 
+// ---- r04: the same two passes as ONE software pipeline per wave -----------------------------------------------------------------
+// hamming_mfma_kernel<KS, *, 4, false> above leaves the overlap of a tile's epilogue with matrix work to the OTHER waves of the SIMD
+// (waves 4-7 run theirs one entry late).  Knock-outs at 256 bit (10 000 x 59 047, k = 11; tools/hm_probe_run.sh) showed what that
+// costs once the matrix work no longer dominates: matrix work + the eight maxima 65 us, + compare / branch of the usual exit 83 us,
+// everything 153 us -- and neither the barrier nor the LDS-DMA is in it (without them: 164 / 80 us).  Every tile's maxima wait for
+// the tile's last MFMA, every branch on them for the maxima, and four waves per SIMD do not hide a chain that each of them has.
+// Here a wave keeps TWO accumulator sets: the detection of tile t - 1 (eight v_max3 and the compare, straight-line, results in
+// scalar registers long before they are branched on) is interleaved instruction by instruction with the dependent MFMA chain of
+// tile t, whose gaps it fills; only a tile with a hit leaves the straight line, after the chain of the next tile has been issued.
+// All waves run the same program (no late half), the padding rows of the table's end are handled by a separate tail loop (the
+// in-place masking made the compiler copy all 16 accumulators in front of every epilogue), and the per-tile code is a quarter of
+// the old loop body.  Same arithmetic, same candidate columns, same results bit for bit.
+// code sizes the pipelined kernels serve, and their ring depth in tiles (24 KiB beside the 56 KiB of candidate columns: two
+// workgroups per CU)
+template <int KS> struct PipeServed { static constexpr bool value = KS == 4 || KS == 8; };
+template <int KS> struct PipeRing { static constexpr int value = KS <= 4 ? 24 / KS : 3; };
+
+template <int KS, int MODE>
+__global__ __launch_bounds__(512, 4) void hamming_pipe_kernel(HArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int KM = 4;
+    constexpr int NB = PipeRing<KS>::value;                 // ring of single tiles
+    constexpr int PD = NB - 1;                              // tiles requested ahead
+    constexpr int TILE_BYTES = KS * 1024;
+    static_assert(KS <= WAVES, "one LDS-DMA piece per wave and tile");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+#if PS_HM_DEBUG & 512
+    const unsigned long long ps_t_start = __builtin_readcyclecounter();
+#endif
+
+    const int G = gridDim.x, b = blockIdx.x;                // XCD-aware block order (see hamming_mfma_kernel)
+    const int gq = G >> 3, gr = G & 7, xcd = b & 7;
+    const int logical = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (b >> 3);
+    const int slice = logical / a.nqb, qb = logical - slice * a.nqb;
+    const int64_t qtile = (int64_t)qb * WAVES + wv;
+    const int64_t nqtiles = (a.nq + 31) >> 5;
+    const int64_t q = qtile * 32 + li;
+    const bool q_ok = q < a.nq;
+
+    int64_t t0 = a.tile_begin + (int64_t)slice * a.tiles_per_slice;
+    int64_t t1 = t0 + a.tiles_per_slice;
+    if (t1 > a.tile_end) t1 = a.tile_end;
+    const int nt = t1 > t0 ? (int)(t1 - t0) : 0;            // tiles of this slice (the plane table is padded to whole PAD_TILES)
+    const int64_t last_tile = (a.N - 1) >> 5;               // tiles from here on hold padding rows
+    const int64_t last_rel64 = last_tile - t0;
+    const int last_rel = last_rel64 > 0x7fffffff ? 0x7fffffff : last_rel64 < 0 ? 0 : (int)last_rel64;
+    const int n_main = (last_rel < nt ? last_rel : nt) & ~1;  // leading tiles free of padding rows, an even number
+
+    v4i bq[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        bq[s] = v4i{0, 0, 0, 0};
+        if (qtile < nqtiles) bq[s] = *reinterpret_cast<const v4i *>(a.qplanes + ((qtile * KS + s) * 64 + lane) * 16);
+    }
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+    const bool loader = wv < KS;                            // waves 0 .. KS - 1 bring in one 1 KiB piece of every tile
+    auto prefetch = [&](int t) __attribute__((always_inline)) {
+        if (loader) lds_dma16(a.dbplanes + (((t0 + (int64_t)t) * KS + wv) * 64 + lane) * 16, lds_base + (uint32_t)((t % NB) * KS + wv) * 1024u);
+    };
+
+    const int CAP = a.cap;
+    uint32_t *cand = reinterpret_cast<uint32_t *>(smem + NB * TILE_BYTES) + wv * (CAP * 64);  // [slot][lane]
+    int cnt = 0;
+    constexpr float BIAS = 3072.0f;                         // see hamming_mfma_kernel: v = BIAS + dot + r / 16
+    float thr = 3.0e38f;
+    float best[KM];
+    v16f cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = MODE == 1 ? BIAS + (float)r * 0.0625f : 0.f;
+    if (MODE == 1) {
+        if (q_ok && !(PS_HM_DEBUG & 64)) thr = BIAS + (float)(a.nbits - 2 * a.thr0[q]);     // 64: nothing passes (the usual exit only)
+    } else {
+#pragma unroll
+        for (int j = 0; j < KM; ++j) best[j] = NO_DOT;
+    }
+    // Candidate keys of this kernel: [2047 - d (11 bits) | tile index in the slice (17 bits) | r (4 bits)] with d = 1024 + dot and r the
+    // row code of the element -- three fields cut straight out of the element's float bits (v = 2048 + d + r / 16 has d in mantissa
+    // bits 12..22 and r in bits 8..11: a shift, a bit-field extract, a bit-field insert and an inversion instead of the nine
+    // instructions of the (distance, row id) key above).  Ascending keys = ascending distance, then ascending id WITHIN a lane (for a
+    // fixed lane half the id grows with (tile, r)); the ids of a query's two lanes interleave (id = 32 tile + 8 (r >> 2) + 4 lh +
+    // (r & 3)), so the lists are rewritten as (distance << shift | row id) keys before the two lanes merge.
+#if PS_HM_DEBUG & 512
+    int ps_dbg_appends = 0, ps_dbg_compactions = 0;
+#endif
+    auto wave_max = [&](int v) __attribute__((always_inline)) -> int {
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
+        return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+                   max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    };
+    // exact: a lane's column -> its k smallest keys in slots 0..k-1, ascending (selection in LDS, bounded by the fullest column of
+    // the wave); the threshold is tightened when the column holds k keys
+    auto compact = [&]() __attribute__((always_inline)) {
+        const int k = a.k;
+        const int mx = wave_max(cnt);
+        const int kk = k < mx ? k : mx;
+        for (int p = 0; p < kk; ++p) {
+            uint32_t bestk = (p < cnt) ? cand[p * 64 + lane] : EMPTY_KEY;
+            const uint32_t head = bestk;
+            int bj = p;
+            for (int j = p + 1; j < mx; ++j) {
+                const uint32_t v = (j < cnt) ? cand[j * 64 + lane] : EMPTY_KEY;
+                if (v < bestk) { bestk = v; bj = j; }
+            }
+            if (p < cnt) {
+                cand[bj * 64 + lane] = head;
+                cand[p * 64 + lane] = bestk;
+            }
+        }
+        cnt = cnt < k ? cnt : k;
+        if (cnt == k) {                                     // only a strictly larger dot can still enter: d >= d_k + 2 (dots share their parity)
+            const int dk = 2047 - (int)(cand[(k - 1) * 64 + lane] >> 21);
+            const float nthr = (float)(2048 + dk + 2);
+            thr = nthr > thr ? nthr : thr;
+        }
+    };
+    // Making room DURING the sweep (a column has filled up: its query's bound came out loose).  The selection above walks the column
+    // in LDS serially, ~30 K cycles with the whole workgroup waiting at its barrier -- tools/hm_times.py showed the few workgroups
+    // that hold such a query setting the kernel's time (260 K cycles against 175-195 K for a CU's pair).  Here the column goes to
+    // registers once; the k-th smallest DISTANCE field T is found by bisection (11 steps of compare-and-count over the registers,
+    // per lane); keys with a distance beyond T are dropped, the survivors (>= k, plus ties at T) are written back in their
+    // order, and the threshold moves to "strictly better than T".  Exact: everything dropped is beaten by k kept keys, and later
+    // items (larger ids) that only tie T cannot displace them.  Only if ties leave no room is the serial selection used.
+    auto compact_in_sweep = [&](int need) __attribute__((always_inline)) {
+        const int k = a.k;
+#if PS_HM_DEBUG & 512
+        ++ps_dbg_compactions;
+#endif
+        const int mx = wave_max(cnt);                       // slots to look at (the fullest column of the wave)
+        // (the column is re-read from LDS in every step: 28 keys in registers beside the two accumulator sets spill, and scratch
+        // traffic inside the counted-vmcnt ring is what tools/check_asm_contracts.py exists to refuse; the reads of a step are
+        // independent of each other, so a step costs one LDS round trip, not `mx` of them)
+        int lo = 0, hi = 2047;
+#pragma unroll 1
+        for (int it = 0; it < 11; ++it) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+#pragma unroll 4
+            for (int j = 0; j < mx; ++j) {
+                const uint32_t key = cand[j * 64 + lane];
+                c += (j < cnt && (int)(key >> 21) <= mid) ? 1 : 0;
+            }
+            if (c >= k) hi = mid; else lo = mid + 1;
+        }
+        const bool full = cnt >= k;                         // lanes with fewer than k keys keep everything
+        int nkeep = 0;
+#pragma unroll 4
+        for (int j = 0; j < mx; ++j) {
+            const uint32_t key = cand[j * 64 + lane];
+            nkeep += (j < cnt && (!full || (int)(key >> 21) <= lo)) ? 1 : 0;
+        }
+        if (__ballot(nkeep > CAP - need) != 0ull) { compact(); return; }       // ties at T fill the column: exact selection by id
+        int pos = 0;
+#pragma unroll 1
+        for (int j = 0; j < mx; ++j) {                      // in place: pos <= j, a slot is read before anything is written to it
+            const uint32_t key = cand[j * 64 + lane];
+            if (j < cnt && (!full || (int)(key >> 21) <= lo)) { cand[pos * 64 + lane] = key; ++pos; }
+        }
+        cnt = pos;
+        if (full) {
+            const float nthr = (float)(2048 + (2047 - lo) + 2);
+            thr = nthr > thr ? nthr : thr;
+        }
+    };
+    auto append_bits = [&](uint32_t bits, uint32_t tile4) __attribute__((always_inline)) {   // tile4 = tile index << 4 (a scalar)
+        const uint32_t tw = ((bits >> 8) & 15u) | tile4;
+        const uint32_t key = ((0xffe00000u & (bits << 9)) | (~0xffe00000u & tw)) ^ 0xffe00000u;
+        cand[cnt * 64 + lane] = key;
+        ++cnt;
+#if PS_HM_DEBUG & 512
+        ++ps_dbg_appends;
+#endif
+    };
+
+    // what the straight-line part leaves behind for a tile: the lane maximum and the wave's two verdicts as SCALARS (`any`: some lane
+    // has a hit / a list that changes; `any2`: some lane has a second hit in this tile), computed in the MFMA gaps long before they
+    // are branched on -- no branch of the per-tile path waits for a vector compare
+    struct Det { float m; unsigned long long any, any2; bool appended; };   // appended: the lane maximum went into the column in the MFMA gaps
+    int cmax = 0;                                           // wave-uniform upper bound of the lanes' column fill
+    // the part of a tile's epilogue that runs only when some lane of the wave has something to do; `i` = the tile's index relative to t0
+    auto finish = [&](const v16f &acc, const Det &d, int i) __attribute__((always_inline)) {
+        if (d.any == 0ull) return;
+        if (MODE == 0) {
+            float x = d.m;
+#pragma unroll
+            for (int j = 0; j < KM; ++j) {
+                const float hi = fmaxf(best[j], x);
+                x = fminf(best[j], x);
+                best[j] = hi;
+            }
+            return;
+        }
+        const uint32_t base = (uint32_t)i << 4;
+        // Room in the columns is scalar bookkeeping: `cmax` bounds every lane's fill from above, and the lanes are asked (and, if one
+        // of them is really that full, compacted) only when the bound says that the next append might not fit.  A compaction is a
+        // serial selection over a lane's column in LDS, ~30 K cycles during which the whole workgroup waits at its barrier
+        // (tools/hm_times.py: the ~60 workgroups of a 480-workgroup launch that compacted once or more set the kernel's time, 296 K
+        // cycles against 190 K for the rest, when room for a whole tile -- 16 rows per lane -- was demanded after every tile); the
+        // usual tile appends ONE key per lane, so room for one is what the next tile needs, and a walk makes room for its own 16.
+        auto make_room = [&](int need) __attribute__((always_inline)) {
+            cmax = wave_max(cnt);
+            if (cmax > CAP - need) {
+                compact_in_sweep(need);
+                cmax = wave_max(cnt);
+            }
+        };
+        if (d.any2 == 0ull) {                               // the usual hit: one element per lane, its maximum, appended in the MFMA gaps
+            if (!d.appended && d.m >= thr) append_bits(__float_as_uint(d.m), base);
+            cmax += 1;
+        } else {                                            // rare (~1 % of the tiles): every passing element of the lane but the maximum, which is in
+            const uint32_t mb = __float_as_uint(d.m);       // (an element carries its row in its fraction bits: no two of a lane are equal)
+            if (cmax > CAP - 16) {                          // might not fit: count what each lane is about to append, compact only if some column really overflows
+                int nl = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nl += (acc[r] >= thr && !(d.appended && __float_as_uint(acc[r]) == mb)) ? 1 : 0;
+                if (__ballot(cnt + nl > CAP) != 0ull) compact_in_sweep(16);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (acc[r] >= thr && !(d.appended && __float_as_uint(acc[r]) == mb)) append_bits(__float_as_uint(acc[r]), base);
+            cmax += 16;
+        }
+        if (cmax > CAP - 1) make_room(1);
+    };
+    // A second hit of a lane in this tile (exact, see hamming_mfma_kernel): two distinct rows differ in r / 3 or in r % 3, so it
+    // exists iff the second-largest maximum over the triples {3 j ..} (sg) or over the residue classes {r % 3 = j} (sh) passes.
+#define PS_MAX3(A, B, C) fmaxf(fmaxf(A, B), C)
+    auto detect_all = [&](const v16f &x, Det &d) __attribute__((always_inline)) {
+        const float a0 = PS_MAX3(x[0], x[1], x[2]), a1 = PS_MAX3(x[3], x[4], x[5]), a2 = PS_MAX3(x[6], x[7], x[8]);
+        const float a3 = PS_MAX3(x[9], x[10], x[11]), a4 = PS_MAX3(x[12], x[13], x[14]), a5 = x[15];
+        const float mu = PS_MAX3(a0, a1, a2), mv = PS_MAX3(a3, a4, a5);
+        d.m = fmaxf(mu, mv);
+        d.appended = false;
+        if (MODE == 0) { d.any = __ballot(d.m > best[KM - 1]); d.any2 = 0ull; return; }
+        d.any = __ballot(d.m >= thr);
+        const float sg = PS_MAX3(fminf(mu, mv), __builtin_amdgcn_fmed3f(a0, a1, a2), __builtin_amdgcn_fmed3f(a3, a4, a5));
+        const float h0 = fmaxf(PS_MAX3(x[0], x[3], x[6]), PS_MAX3(x[9], x[12], x[15]));
+        const float h1 = PS_MAX3(PS_MAX3(x[1], x[4], x[7]), x[10], x[13]);
+        const float h2 = PS_MAX3(PS_MAX3(x[2], x[5], x[8]), x[11], x[14]);
+        d.any2 = __ballot(fmaxf(sg, __builtin_amdgcn_fmed3f(h0, h1, h2)) >= thr);
+    };
+    // the MFMA chain of one tile into `w`, the detection of the previous tile `x` in its gaps: 23 vector instructions behind the
+    // first four MFMAs (the gap of a 32 x 32 x 64 fp4 MFMA leaves room for about six).  sched_barrier(0) pins the interleaving;
+    // PIN: an empty volatile asm that names the accumulator keeps each MFMA at its place -- the results are not needed before the
+    // next tile's detection, and without it the compiler sinks the whole chain below the branches of `finish`.
+#define PS_PIN(W) asm volatile("" : "+v"(W))
+    // The usual hit (one passing element per lane: its maximum) is appended right there, predicated, between the third and the
+    // fourth MFMA: every wave of the workgroup then runs the same instructions tile after tile whether it has a hit or not, and
+    // nobody arrives late at the next barrier (r04 measurement with the append behind a branch after the chain: sweep with the
+    // usual exit only 82 us, complete 142 us -- 2/3 of the wave-tiles have a hit, so every barrier interval had a late wave).
+    // Fragments: four registers sets of 16 bytes; 512-bit codes (KS = 8) request the second half into the same registers once the
+    // first four MFMAs have been issued (32 fragment registers beside two accumulator sets, the row constants and 32 query registers
+    // do not fit the 128 of a four-waves-per-SIMD kernel).
+    auto pipe_tile = [&](v16f &w, const unsigned char *tb, const v16f &x, Det &d, int xi) __attribute__((always_inline)) {
+        v4i av[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) av[s] = *reinterpret_cast<const v4i *>(tb + s * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        w = MODE == 1 ? sign_mfma_first(av[0], bq[0], cinit, 0x7f7f7f7f) : sign_mfma(av[0], bq[0], cinit);
+        PS_PIN(w);
+        const float a0 = PS_MAX3(x[0], x[1], x[2]), a1 = PS_MAX3(x[3], x[4], x[5]), a2 = PS_MAX3(x[6], x[7], x[8]);
+        const float a3 = PS_MAX3(x[9], x[10], x[11]), a4 = PS_MAX3(x[12], x[13], x[14]), a5 = x[15];
+        __builtin_amdgcn_sched_barrier(0);
+        w = sign_mfma(av[1], bq[1], w);
+        PS_PIN(w);
+        const float mu = PS_MAX3(a0, a1, a2), mv = PS_MAX3(a3, a4, a5);
+        d.m = fmaxf(mu, mv);
+        d.any = MODE == 1 ? __ballot(d.m >= thr) : __ballot(d.m > best[KM - 1]);
+        d.any2 = 0ull;
+        d.appended = MODE == 1;
+        float sg = 0.f;
+        if (MODE == 1) sg = PS_MAX3(fminf(mu, mv), __builtin_amdgcn_fmed3f(a0, a1, a2), __builtin_amdgcn_fmed3f(a3, a4, a5));
+        __builtin_amdgcn_sched_barrier(0);
+        w = sign_mfma(av[2], bq[2], w);
+        PS_PIN(w);
+        if (MODE == 1) {
+            if (d.m >= thr) append_bits(__float_as_uint(d.m), (uint32_t)xi << 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        w = sign_mfma(av[3], bq[3], w);
+        PS_PIN(w);
+        if constexpr (KS == 8) {                            // the second half of the fragments into the same registers
+#pragma unroll
+            for (int s = 0; s < 4; ++s) av[s] = *reinterpret_cast<const v4i *>(tb + (4 + s) * 1024);
+        }
+        if (MODE == 1) {                                    // the residue classes' maxima: eight instructions, three live values
+            const float h0 = fmaxf(PS_MAX3(x[0], x[3], x[6]), PS_MAX3(x[9], x[12], x[15]));
+            const float h1 = PS_MAX3(PS_MAX3(x[1], x[4], x[7]), x[10], x[13]);
+            const float h2 = PS_MAX3(PS_MAX3(x[2], x[5], x[8]), x[11], x[14]);
+            d.any2 = __ballot(fmaxf(sg, __builtin_amdgcn_fmed3f(h0, h1, h2)) >= thr);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KS == 8) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { w = sign_mfma(av[s], bq[4 + s], w); PS_PIN(w); }
+        }
+    };
+#undef PS_PIN
+#undef PS_MAX3
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): query fragments / bounds are in; from here on the ring counts
+    // Ring of NB single tiles, PD = NB - 1 requested ahead.  Step t: own piece of tile t landed -> barrier: everybody's have, and
+    // everybody is past the MFMA chain of tile t - 1, i.e. done with its fragments' buffer, which the request for tile t + PD
+    // overwrites -> the tile's KS fragments are requested and the MFMA chain runs behind them (each MFMA waits for its own fragment
+    // only), with the detection of tile t - 1 in its gaps -> whatever tile t - 1 left to do.
+    // (r04 variants measured at 256 bit, sweep with the usual exit only / complete: two-tile entries read and awaited in front of the
+    // entry's MFMAs 80 / 136 us; single tiles with the next tile's fragments requested one step ahead into a second register set
+    // 85 / 152 us -- the LDS round trip was not what the waves wait for, and its 16 registers are what the steady-state loop needs.)
+#pragma unroll
+    for (int j = 0; j < PD; ++j)
+        if (j < nt) prefetch(j);
+    v16f accA, accB;                                        // accumulators of the even / odd tiles
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accA[r] = MODE == 1 ? 0.f : NO_DOT; accB[r] = MODE == 1 ? 0.f : NO_DOT; }   // "tile -1": no hit, no list change
+    // tile `t` readable: own piece landed (at most the PD - 1 younger requests still in flight), barrier, next request, fragments
+    auto open_tile = [&](int t) __attribute__((always_inline)) -> const unsigned char * {
+        if (nt - 1 - t >= PD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD - 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + PD < nt) prefetch(t + PD);
+        return smem + (t % NB) * TILE_BYTES + lane * 16;
+    };
+    auto mask_padding = [&](v16f &w, int i) __attribute__((always_inline)) {
+        const int64_t left64 = a.N - (t0 + i) * 32;         // valid rows of this tile (<= 0: a padding tile of the table's end)
+        const int left = (int)(left64 < 0 ? 0 : left64 > 32 ? 32 : left64) - 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if ((r & 3) + 8 * (r >> 2) >= left) w[r] = MODE == 1 ? 0.f : NO_DOT;
+    };
+    Det d;
+    int t = 0;
+    // Steady state, two tiles per trip (one per accumulator set): the vmcnt literal is a constant, the plane table is addressed by a
+    // scalar base that advances one tile per step (LDS-DMA in its scalar-base form: no vector address arithmetic) and the ring
+    // slots by two scalar offsets that wrap by compare-and-select -- nothing is computed modulo NB.  (The generic loops below spend
+    // ~28 scalar and 5 vector instructions per tile on that bookkeeping.  A version that unrolled 2 NB steps with constant slots
+    // was no faster and grew the kernel to 70 KB of code, more than the instruction cache two CUs share: half of the workgroups
+    // took 185 K cycles instead of 135 K, tools/hm_times.py.)
+    {
+        int n_steady = n_main < nt - PD ? n_main : nt - PD;
+        n_steady = n_steady > 0 ? n_steady & ~1 : 0;
+        const uint32_t voff = (uint32_t)(wv * 1024 + lane * 16);          // this lane's 16 bytes inside a tile of the plane table
+        const unsigned char *gnext = a.dbplanes + ((t0 + PD) * (int64_t)KS) * 1024;      // tile t + PD
+        const uint32_t lds_w = lds_base + (uint32_t)wv * 1024u;
+        const uint32_t frag = lds_base + (uint32_t)lane * 16u;
+        uint32_t rd = 0, fill = (uint32_t)((PD % NB) * TILE_BYTES);        // ring offsets of tile t and of tile t + PD
+        auto steady_step = [&](v16f &w, const v16f &x, int xi) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD - 1) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (loader)
+                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gnext), "s"(lds_w + fill) : "memory", "m0");
+            gnext += TILE_BYTES;
+            const unsigned char *tb = reinterpret_cast<const unsigned char *>(smem) + ((frag + rd) - lds_base);
+            rd = rd + TILE_BYTES == (uint32_t)(NB * TILE_BYTES) ? 0u : rd + TILE_BYTES;
+            fill = fill + TILE_BYTES == (uint32_t)(NB * TILE_BYTES) ? 0u : fill + TILE_BYTES;
+            pipe_tile(w, tb, x, d, xi);
+            finish(x, d, xi);
+        };
+        for (; t < n_steady; t += 2) {
+            steady_step(accA, accB, t - 1);
+            steady_step(accB, accA, t);
+        }
+    }
+    for (; t < n_main; t += 2) {                            // tiles t, t + 1 < n_main <= nt
+        pipe_tile(accA, open_tile(t), accB, d, t - 1);      // tile t, detection of tile t - 1
+        finish(accB, d, t - 1);
+        pipe_tile(accB, open_tile(t + 1), accA, d, t);      // tile t + 1, detection of tile t
+        finish(accA, d, t);
+    }
+    // the slice's last tiles: those that hold padding rows are masked before anybody looks at them (a few per launch; same ring
+    // protocol, the masking is what the loops above are spared)
+    for (; t < nt; t += 2) {
+        pipe_tile(accA, open_tile(t), accB, d, t - 1);
+        if (t >= last_rel) mask_padding(accA, t);
+        finish(accB, d, t - 1);
+        if (t + 1 < nt) {
+            pipe_tile(accB, open_tile(t + 1), accA, d, t);
+            if (t + 1 >= last_rel) mask_padding(accB, t + 1);
+            finish(accA, d, t);
+        } else {                                            // an odd tile count: tile t is the last one
+            detect_all(accA, d);
+            finish(accA, d, t);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[r] = MODE == 1 ? 0.f : NO_DOT;     // nothing pending
+        }
+    }
+    if (nt > 0) {                                           // the tile still in flight (none when the count was odd: accB is blank)
+        detect_all(accB, d);
+        finish(accB, d, nt - 1);
+    }
+
+    // ---- results (as hamming_mfma_kernel) ----
+    // (the query index is derived again from a thread id the compiler cannot connect with the one of the prologue: kept alive across
+    // the sweep it was the one value that no longer fitted the 128 registers at 512 bit -- and a spill is scratch traffic in a kernel
+    // whose vmcnt literals count every vector-memory request)
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int li2 = tid2 & 31, lh2 = (tid2 >> 5) & 1, lane2 = tid2 & 63;
+    const int64_t q2 = qtile * 32 + li2;
+    const bool q2_ok = q2 < a.nq;
+    if (MODE == 0) {
+        if (q2_ok) {
+            int32_t *dst = a.bl + ((int64_t)q2 * (a.slices * 2) + slice * 2 + lh2) * KM;
+#pragma unroll
+            for (int j = 0; j < KM; ++j) dst[j] = best[j] == NO_DOT ? 0x7fffffff : (a.nbits - (int)best[j]) >> 1;
+        }
+        return;
+    }
+#if PS_HM_DEBUG & 512
+    const unsigned ps_dbg_app_sum = (unsigned)ps_wave_sum_i32(ps_dbg_appends);
+    if (MODE == 1 && lane2 == 0 && blockIdx.x < 4096)       // the busiest wave's appends / in-sweep compactions (bits 32.., 56..)
+        atomicMax(&ps_hm_times[4 * blockIdx.x + 2], ((unsigned long long)(ps_dbg_app_sum & 0xffffffu) << 32) | ((unsigned long long)(unsigned)ps_dbg_compactions << 56));
+    if (MODE == 1 && tid == 0 && blockIdx.x < 4096) {
+        ps_hm_times[4 * blockIdx.x] = ps_t_start; ps_hm_times[4 * blockIdx.x + 1] = __builtin_readcyclecounter();
+        atomicOr(&ps_hm_times[4 * blockIdx.x + 2], (unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4));      // HW_ID
+        ps_hm_times[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) | ((unsigned long long)slice << 32) | ((unsigned long long)qb << 48);   // XCC_ID, slice, query block
+    }
+#endif
+    compact();
+    for (int p = 0; p < cnt; ++p) {                         // (distance << shift | row id in the slice) keys: comparable across the two lanes
+        const uint32_t key = cand[p * 64 + lane2];
+        const int dot = 2047 - (int)(key >> 21) - 1024;
+        const uint32_t r = key & 15u, tile = (key >> 4) & 0x1ffffu;
+        cand[p * 64 + lane2] = ((uint32_t)((a.nbits - dot) >> 1) << a.shift) | (tile * 32u + 4u * lh2 + (r & 3u) + 8u * (r >> 2));
+    }
+    ps_wave_lds_sync();
+    const int cnt_hi = __shfl(cnt, li2 + 32, 64);
+    if (q2_ok && lh2 == 0) {
+        const uint32_t idmask = (1u << a.shift) - 1u;
+        const int64_t o = ((int64_t)(a.list_base + slice) * a.nq + q2) * a.k;
+        int ia = 0, ib = 0;
+        for (int p = 0; p < a.k; ++p) {
+            const uint32_t ka = ia < cnt ? cand[ia * 64 + lane2] : EMPTY_KEY;
+            const uint32_t kb = ib < cnt_hi ? cand[ib * 64 + lane2 + 32] : EMPTY_KEY;
+            const uint32_t key = ka < kb ? ka : kb;
+            if (ka < kb) ++ia; else ++ib;
+            const bool has = key != EMPTY_KEY;
+            a.out_d[o + p] = has ? (int32_t)(key >> a.shift) : 0x7fffffff;
+            a.out_r[o + p] = has ? (int32_t)((key & idmask) + (uint32_t)(t0 * 32)) : -1;
+        }
+    }
+}
+
 // Final merge of the per-slice lists: 16 lanes per query, lane j = the head of slice j's sorted list; k rounds of
 // "row minimum of the 64-bit keys distance << 32 | table row" (4 DPP exchange steps, no LDS), the winner advances.
 // One wave = 4 queries.  ids = row + id_offset; missing entries (-1, INT32_MAX) like faiss.
@@ -710,6 +1167,8 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
         // four-tile entries do not fit 128 VGPRs -- those instantiations spilled and were never launched: not built any more)
         if constexpr (KS >= 4)
             lds_ok = lds_ok && allow_lds(hamming_mfma_kernel<KS, 1, 4, false>, 80 * 1024) && allow_lds(hamming_mfma_kernel<KS, 0, 4, false>, 80 * 1024);
+        if constexpr (PipeServed<KS>::value)
+            lds_ok = lds_ok && allow_lds(hamming_pipe_kernel<KS, 1>, 80 * 1024) && allow_lds(hamming_pipe_kernel<KS, 0>, 80 * 1024);
         lds_done.set(devid, lds_ok ? 1 : 0);
     }
     if (!lds_ok) return PS_ELAUNCH;
@@ -720,8 +1179,16 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
     b.tile_begin = 0; b.tile_end = p.sample_tiles; b.tiles_per_slice = p.btiles_per_slice; b.slices = p.bslices; b.bl = bl;
     const unsigned gb = (unsigned)(p.nqb * p.bslices);
     bool launched = false;
+    // 0: the r03 kernels (cross-check / experiments); the pipelined kernels' keys hold a 17-bit tile index per slice
+    const bool pipe = PipeServed<KS>::value && env_int("PS_HAMMING_PIPE", 1) != 0 && p.tiles_per_slice <= (1 << 17) && p.btiles_per_slice <= (1 << 17);
+    if constexpr (PipeServed<KS>::value) {
+        if (p.km == 4 && !p.db && pipe) {
+            hipLaunchKernelGGL((hamming_pipe_kernel<KS, 0>), dim3(gb), dim3(512), (size_t)PipeRing<KS>::value * KS * 1024, st, b);
+            launched = true;
+        }
+    }
     if constexpr (KS >= 4) {
-        if (p.km == 4 && !p.db) {
+        if (!launched && p.km == 4 && !p.db) {
             hipLaunchKernelGGL((hamming_mfma_kernel<KS, 0, 4, false>), dim3(gb), dim3(512), (size_t)3 * IT1 * KS * 1024, st, b);
             launched = true;
         }
@@ -745,8 +1212,14 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
     a.list_base = 0;
     const unsigned gc = (unsigned)(p.nqb * p.slices);
     bool collected = false;
+    if constexpr (PipeServed<KS>::value) {
+        if (!p.db && pipe) {
+            hipLaunchKernelGGL((hamming_pipe_kernel<KS, 1>), dim3(gc), dim3(512), (size_t)PipeRing<KS>::value * KS * 1024 + (size_t)WAVES * p.cap * 64 * sizeof(uint32_t), st, a);
+            collected = true;
+        }
+    }
     if constexpr (KS >= 4) {
-        if (!p.db) {
+        if (!collected && !p.db) {
             hipLaunchKernelGGL((hamming_mfma_kernel<KS, 1, 4, false>), dim3(gc), dim3(512), lds, st, a);
             collected = true;
         }

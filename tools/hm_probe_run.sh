@@ -8,8 +8,8 @@ for bits in "$@"; do
 import csv
 out=[]
 for r in csv.DictReader(open('gpurun_out/prof_p$bits/p_kernel_stats.csv')):
-    if 'hamming_mfma_kernel' in r['Name']:
-        out.append(('collect' if ', 1, ' in r['Name'] else 'bound', round(float(r['AverageNs'])/1e3,1)))
+    if 'hamming_mfma_kernel' in r['Name'] or 'hamming_pipe_kernel' in r['Name']:
+        out.append(('collect' if (', 1, ' in r['Name'] or ', 1>' in r['Name']) else 'bound', round(float(r['AverageNs'])/1e3,1)))
 print('bits=$bits', out)
 PY
 done
