@@ -386,12 +386,12 @@ def main():
             roofline["bound"] = "hbm"          # the contract's vocabulary; the on-die bound is named in kernels[*]
         # device kernels behind each C-ABI call (the rows of profiles/*/kernel_stats.csv the timings agree with)
         symbols = {"ps_walk_sample_layers": ["walk_sample_kernel<4, STREAM>"], "ps_walk_sample": ["walk_sample_kernel<4, STREAM>"],
-                   "ps_importance_pool": ["importance_pool_kernel<4>"],
+                   "ps_importance_pool": ["importance_pool4_kernel<PAGES> (four output rows per wave; T <= 64)"],
                    "ps_linear": ["gemm_f32_pkernel<2,2,1,2,32,0> (input_proj: no row norm, 64x128 tiles, persistent)",
                                  "gemm_f32_kernel<1,4,2,2,32,0,true> (layers + output_proj: fused L2 norm, 64x256 tiles)"],
                    "ps_lsh_encode": ["gemm_f32_pkernel<2,2,1,2,32,1>"],
-                   "ps_hamming_topk_mfma": ["hamming_mfma_kernel<KS, 0, 4, false> (bound)", "bound_select_kernel",
-                                            "hamming_mfma_kernel<KS, 1, 4, false> (collect)", "slice_merge_kernel"],
+                   "ps_hamming_topk_mfma": ["hamming_pipe_kernel<KS, 0> (bound)", "bound_select_kernel",
+                                            "hamming_pipe_kernel<KS, 1> (collect)", "slice_merge_kernel"],
                    "ps_hamming_topk": ["hamming_scan_kernel<16,4>", "topk_rank_merge_kernel"],
                    "ps_mt19937_raw_stream": ["mt_begin", "mt_planes", "mt_jump_mfma", "mt_jump_reduce", "mt_jump_finish", "mt_chunk (both directions)"],
                    "ps_mt19937_random_sample": ["mt_* (jump-ahead windows + chunk generators + mt_raw_to_double)"]}

@@ -20,28 +20,32 @@
 // contraction is over matching bits whatever k permutation the hardware applies inside a step.
 //
 // Three passes (all exact; no host synchronisation):
-//   bound   : over the first `sample` items every lane keeps the KM best "maximum dot of a 16-item group" values
-//             (KM = 4 when a query's sample is seen by enough lanes; the insertion network runs only for tiles in which some
-//             lane's list changes); the k-th smallest group minimum over a query's lanes bounds its k-th best distance from
-//             above (k distinct groups = k distinct items).
-//   collect : over ALL items, a 32 x 32 tile of dots is KS MFMAs; lane = query, registers = items, so the admission
-//             test is ONE per-lane threshold: an 11-instruction max tree + compare.  The accumulators start at
-//             BIAS + r / 16, so an element carries its row in its fraction bits and the maximum of a hit lane is appended
-//             to the lane's candidate column without looking at the other 15; a second hit in the same lane and tile is
-//             detected exactly by two second-largest-group-maximum tests and only then are all rows walked.  A column that
-//             fills up is compacted to its k best and the lane's threshold tightened (exact: ids ascend during the sweep).
+//   bound   : over the first fifth of the table every lane keeps the KM best "maximum dot of a 16-item group" values; the k-th
+//             smallest group minimum over a query's lanes (bound_select_kernel) bounds its k-th best distance from above (k distinct
+//             groups = k distinct items).
+//   collect : over ALL items, a 32 x 32 tile of dots is KS MFMAs; lane = query, registers = items, so the admission test is ONE
+//             per-lane threshold.  The accumulators start at BIAS + r / 16, so an element carries its row in its fraction bits and
+//             the maximum of a hit lane is appended to the lane's candidate column without looking at the other 15; a second hit
+//             in the same lane and tile is detected exactly and only then are all rows walked.  A column that would overflow is
+//             compacted and the lane's threshold tightened (exact: ids ascend during the sweep).
 //   merge   : every slice leaves one sorted k-list per query (the two lanes of a query merge theirs in LDS);
 //             slice_merge_kernel merges them by (distance, row): 16 lanes per query, k rounds of a DPP row minimum
 //             (slice_merge64_kernel, one wave per query, when few queries over a large table are cut into 17..64 slices).
-// One workgroup = 8 waves = 256 queries x one slice of the table; item tiles come through a 4-deep LDS ring (LDS-DMA, counted
-// vmcnt, raw s_barrier) and two register sets of item fragments (the ds_reads of entry i + 1 run under the MFMAs of entry i);
-// waves 4-7 run their tile epilogue one entry late so that the two waves of a SIMD alternate between the matrix pipe and
-// the VALU instead of meeting at both.
-// Where the time goes (r03, 10 000 x 59 047 x 512 bit, k = 11; knock-out builds, tools/hm_probe_run.sh): the matrix work with only
-// the eight maxima of the epilogue 115 us (4.73 M MFMAs at the 16 ns a bare loop measures would be 74), + compare and branch of
-// the usual exit 10 us, + the hit path (2/3 of the tiles have a hit in one of the wave's 1 024 elements) 34 us.  At 256 bit the
-// matrix work halves (65 us) but the per-tile parts do not (usual exit 18 us, hit path 70 us): that pass is bound by the
-// epilogue, not by the matrix pipe.
+// Two generations of sweep kernels live here:
+//   hamming_pipe_kernel<KS, MODE>   (r04; 256- and 512-bit codes, k <= 12: the BASELINE configurations) -- two workgroups per CU,
+//       a ring of single tiles, two accumulator sets per wave: the detection of tile t - 1 runs in the gaps of the MFMA chain of
+//       tile t.  10 000 x 59 047, k = 11: 0.128 ms at 256 bit, 0.168 ms at 512 bit (r03: 0.194 / 0.207 on the same box).
+//   hamming_mfma_kernel<KS, MODE, KM, DB>  (r02 / r03; every other served shape: 64- / 128-bit codes, k up to 32) -- 8 waves, a
+//       ring of two- / four-tile entries, waves 4-7 one entry late.
+// What the r04 measurements said about this pass (tools/hm_probe_run.sh knock-outs, tools/hm_pmc.sh counters, tools/hm_times.py
+// per-workgroup stamps), because three plausible theories were wrong first: it is not the barrier (without it: slower), not the
+// LDS round trip of the fragments (requested a tile ahead: no gain), not instruction-cache pressure (a 70 KB unrolled loop and a
+// 20 KB loop ran alike).  A SIMD issues about one instruction per four cycles whatever its kind while four waves run the same code in
+// near lockstep, so the sweep costs its instruction count (~55 per tile and wave with the usual exit, ~70 with a hit) -- and the
+// kernel's time was set by the ~60 of 480 workgroups in which some lane's column overflowed: the serial in-LDS compaction took
+// ~30 K cycles with the whole workgroup at its barrier, because room for a whole tile (16 rows per lane) was demanded after
+// every tile.  Asking only for the room the next append needs, and compacting by bisection when a column really is full, took the
+// 256-bit collect pass from 153 to ~100 us (random codes: 94; the straight-line pipeline and the leaner keys are the rest of it).
 #include "ps_common.h"
 #include <type_traits>
 

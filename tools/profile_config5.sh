@@ -4,7 +4,7 @@
 #   pmc_sampler.txt, pmc_calibration.txt}
 # usage: tools/profile_config5.sh r03   (through gpurun; rocprofv3 gets the program itself after --)
 set -u
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_${R}_config5
 mkdir -p $OUT

@@ -6,7 +6,7 @@
 #   default/pmc_mfma.txt                : MFMA / VALU busy counters
 # usage: tools/profile_round.sh r02   (run through gpurun; rocprofv3 gets the program itself after --)
 set -u
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -30,4 +30,7 @@ python tools/pmc_traffic.py $OUT/default/pmc_FETCH_SIZE $OUT/default/pmc_WRITE_S
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/default/pmc_mfma -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/default/pmc_mfma.err
 python tools/pmc_summary.py $OUT/default/pmc_mfma > $OUT/default/pmc_mfma.txt 2>&1
 rm -rf $OUT/default/pmc_FETCH_SIZE $OUT/default/pmc_WRITE_SIZE $OUT/default/pmc_mfma
+# the Hamming scan alone, three counter passes per code size (tools/hm_pmc.sh)
+bash tools/hm_pmc.sh ${R}_256 256 > /dev/null 2>&1; cp gpurun_out/hm_pmc_${R}_256/summary.txt $OUT/default/pmc_hamming_256bit.txt
+bash tools/hm_pmc.sh ${R}_512 512 > /dev/null 2>&1; cp gpurun_out/hm_pmc_${R}_512/summary.txt $OUT/default/pmc_hamming_512bit.txt
 ls -R $OUT | head -40
