@@ -338,15 +338,23 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
         const float h2 = fmaxf(fmaxf(fmaxf(fmaxf(acc[2], acc[5]), acc[8]), acc[11]), acc[14]);
         const float sh = __builtin_amdgcn_fmed3f(h0, h1, h2);
         const uint32_t base = (uint32_t)i * 32u + 4u * lh;
+        // Room in the columns (r04, see hamming_pipe_kernel): the usual tile appends ONE key per lane, so after a tile only room for
+        // one more is demanded; a walk counts what it is about to append and compacts first only if a column would overflow.
+        // (Demanding room for 16 rows after every tile made ~60 of a launch's 480 workgroups compact -- a serial selection in LDS,
+        // ~30 K cycles with the workgroup at its barrier -- and those workgroups set the kernel's time.)
         if (__ballot(fmaxf(sg, sh) >= thr) == 0ull) {
             if (m >= thr) append_bits(__float_as_uint(m), base);
         } else {
             PS_HM_COUNT(2, 1);
+            int nl = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nl += acc[r] >= thr ? 1 : 0;
+            if (__ballot(cnt + nl > CAP) != 0ull) { PS_HM_COUNT(5, 1); compact(); }      // (k + 16 <= CAP: it fits afterwards)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (acc[r] >= thr) append_bits(__float_as_uint(acc[r]), base);
         }
-        if (__ballot(cnt > CAP - 16) != 0ull) { PS_HM_COUNT(5, 1); compact(); }   // room for one more tile (16 rows per lane) is guaranteed
+        if (__ballot(cnt > CAP - 1) != 0ull) { PS_HM_COUNT(5, 1); compact(); }   // room for the next tile's single append
     };
 
     // ---- sweep ----
