@@ -357,14 +357,14 @@ def main():
                     k["random_sector_rate_Gps"] = traffic[n] / 64.0 / (k["avg_ms"] * 1e-3) / 1e9
                     k["random_sector_peak_Gps"] = RANDOM_SECTOR_PEAK / 1e9
                     k["frac_of_random_sector_peak"] = k["random_sector_rate_Gps"] * 1e9 / RANDOM_SECTOR_PEAK
-        # `roofline`: the C-ABI call with the largest time per step, whatever bounds it; config 5 exists to show the sampler
-        # where it is HBM-bound (the graph is 66 GB, far beyond the 256 MiB Infinity Cache), so there it is the sampler
+        # `roofline`: north_star's roofline target is the sampler (">= 40 % HBM-roofline on the sampler"), which is also the longest
+        # single launch of the step; the C-ABI call with the largest time per step -- ps_linear's FOUR launches together come to
+        # about the same -- is named beside it with its own fraction (`dominant_kernel`, `dominant_frac`), so nothing hides behind
+        # the choice
         dom = max(kern, key=lambda n: kern[n]["ms_per_step"])
-        dominant_call = dom                # the true maximum of ms_per_step, reported beside `roofline.kernel`
-        # a near-tie (the sampler and the four dense launches take 0.44-0.45 ms each) goes to the sampler, the kernel north_star's
-        # roofline target names, so that the line does not flip between runs
+        dominant_call = dom
         smp_call = "ps_walk_sample_layers" if "ps_walk_sample_layers" in kern else "ps_walk_sample"
-        if smp_call in kern and (big or kern[smp_call]["ms_per_step"] >= 0.95 * kern[dom]["ms_per_step"]):
+        if smp_call in kern:
             dom = smp_call
         kd = kern[dom]
         div = 1e9 if kd["bound"] in ("hbm", "valu", "mall") else 1e12
@@ -372,7 +372,8 @@ def main():
         if dom == "ps_hamming_topk_mfma":
             unit = "TOP/s"
         roofline = {"kernel": dom, "dominant_kernel": dominant_call,
-                    "dominant_kernel_ms_per_step": kern[dominant_call]["ms_per_step"], "kernel_ms_per_step": kd["ms_per_step"],
+                    "dominant_kernel_ms_per_step": kern[dominant_call]["ms_per_step"], "dominant_bound": kern[dominant_call]["bound"],
+                    "dominant_frac": kern[dominant_call]["frac"], "kernel_ms_per_step": kd["ms_per_step"],
                     "bound": kd["bound"], "achieved": kd["achieved"] / div, "peak": kd["peak"] / div,
                     "unit": unit, "frac": kd["frac"],
                     "traffic": traffic.get(dom), "traffic_source": traffic.get("source") if dom in traffic else None,

@@ -4,6 +4,8 @@ Replaces RandomWalkSampler._prepare_adjacency_list (reference utils/random_walk.
 the per-step `weights / weights.sum()` + `np.random.choice` CDF (:72-79)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import native as nv
@@ -56,18 +58,22 @@ class DeviceGraph:
             if E:
                 nv.call("ps_pack_edges", nv.ptr(self.col), nv.ptr(self.cdf), nv.ptr(self.guide), nv.i64(E),
                         nv.ptr(self.packed), nv.stream())
-            # bucket records (one sector per later walk step): the 64-byte form when it fits comfortably (4 x the adjacency:
-            # SYN-25M 3.2 GB), the 32-byte half records when only they do (BASELINE config 5: 64 GB beside the 66 GB graph),
-            # nothing otherwise.  buckets = True / "full", "half", False force a form.  The CSR build's sort workspace is
-            # returned first: at 2 x 10^9 edges it is the size of the half records.
+            # bucket records (one sector per later walk step).  Default: the 32-byte half records (four candidates' CDF entries as fp32
+            # lower bounds + destinations) -- measured 5 % FASTER than the 64-byte records on SYN-25M too (0.406 against 0.431 ms per
+            # two-layer launch, same box, alternating runs) at half the memory (1.6 GB instead of 3.2), and the only form that fits
+            # BASELINE config 5 (64 GB beside the 66 GB graph); skipped when even they would not fit.  buckets = "full" / True builds
+            # the 64-byte records (five exact candidates; kept as the cross-check), "half", False force a form.  The CSR build's
+            # sort workspace is returned first: at 2 x 10^9 edges it is the size of the half records.
             del ws
             self.buckets, self.bucket_bytes = None, 0
             if E and buckets is not False:
                 torch.cuda.empty_cache()
                 free = torch.cuda.mem_get_info(dev)[0]
                 form = {True: "full", "full": "full", "half": "half", None: None}[buckets]
+                if form is None and os.environ.get("PS_GRAPH_BUCKETS") in ("full", "half"):     # experiments: force a form
+                    form = os.environ["PS_GRAPH_BUCKETS"]
                 if form is None:
-                    form = "full" if E * 64 < free // 2 else ("half" if E * 32 < (free * 3) // 5 else None)
+                    form = "half" if E * 32 < (free * 3) // 5 else None
                 if form == "full":
                     self.buckets, self.bucket_bytes = torch.empty(E * 64, dtype=torch.uint8, device=dev), 64
                     nv.call("ps_bucket_build", nv.ptr(self.rowptr), nv.ptr(self.col), nv.ptr(self.cdf), nv.ptr(self.guide),

@@ -243,7 +243,7 @@ def test_guide_table_is_exact_on_skewed_weights():
     w = np.exp(rs.uniform(np.log(1e-4), np.log(1e5), size=n)).astype(np.float32)
     w[rs.randint(0, n, size=50)] = 1e7                       # a few dominant edges
     ew = np.concatenate([w, w])
-    g = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew))
+    g = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew), buckets="full")
     cg = co.Graph(ei, ew, threads=4)
     assert np.array_equal(g.cdf.cpu().numpy(), cg.cdf)
     nodes = np.arange(700)
@@ -253,7 +253,7 @@ def test_guide_table_is_exact_on_skewed_weights():
     d = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_guide=True, use_buckets=False)
     e = sampling.walk_sample(g, nodes, 20, 100, 3, rng="philox", seed=5, use_packed=False, use_buckets=False)
     assert g.buckets is not None and g.bucket_bytes == 64    # a: LDS-staged start rows + bucket records
-    gh = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew), buckets="half")     # 32-byte half records (config 5's form)
+    gh = DeviceGraph(torch.from_numpy(ei), torch.from_numpy(ew))                     # the default: 32-byte half records
     assert gh.bucket_bytes == 32 and gh.buckets.numel() == 32 * gh.E
     f = sampling.walk_sample(gh, nodes, 20, 100, 3, rng="philox", seed=5)
     ids, counts, nv, _, _, _ = co.walk_sample(cg, nodes, 20, 3, 100, philox=(5, 0), threads=8)
