@@ -12,7 +12,10 @@ and of the [nq, K] candidates), total work fixed -> "scaling": "strong".
 
 Launch: python bench.py --gpus 1 --steps K --warmup W
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  At N = 1 the line carries `cpu_baseline` (the C oracle + torch CPU on the host cores, the
+whole step) and `parity_check`: that CPU run's outputs compared with one GPU step from the same RNG state -- sampled ids /
+counts of both layers in both RNG modes, the np.random state afterwards, LSH codes and top-k lists bit-exact, embeddings
+within 1e-5; a mismatch exits with status 1 after printing the line.
 """
 import argparse
 import json

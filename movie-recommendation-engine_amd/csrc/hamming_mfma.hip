@@ -719,15 +719,25 @@ __global__ __launch_bounds__(512, 4) void hamming_pipe_kernel(HArgs a) {
             cmax += 1;
         } else {                                            // rare (~1 % of the tiles): every passing element of the lane but the maximum, which is in
             const uint32_t mb = __float_as_uint(d.m);       // (an element carries its row in its fraction bits: no two of a lane are equal)
+            bool have_m = d.appended;
             if (cmax > CAP - 16) {                          // might not fit: count what each lane is about to append, compact only if some column really overflows
                 int nl = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) nl += (acc[r] >= thr && !(d.appended && __float_as_uint(acc[r]) == mb)) ? 1 : 0;
-                if (__ballot(cnt + nl > CAP) != 0ull) compact_in_sweep(16);
+                for (int r = 0; r < 16; ++r) nl += (acc[r] >= thr && !(have_m && __float_as_uint(acc[r]) == mb)) ? 1 : 0;
+                if (__ballot(cnt + nl > CAP) != 0ull) {
+                    // A compaction tightens the threshold to "strictly better than the k-th kept key" because every LATER item has
+                    // a larger id -- true at a tile boundary only.  This tile's maximum went in already (the element with the
+                    // LARGEST row of the lane's ties), and the rows still to come tie it with smaller ids: take it back (it is the
+                    // lane's last key), compact what the earlier tiles left, then append every passing element of this tile.
+                    // (tests/test_hip_hamming_mfma.py::test_columns_that_fill_up_during_the_sweep found the other order wrong.)
+                    if (have_m && d.m >= thr) --cnt;
+                    have_m = false;
+                    compact_in_sweep(16);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (acc[r] >= thr && !(d.appended && __float_as_uint(acc[r]) == mb)) append_bits(__float_as_uint(acc[r]), base);
+                if (acc[r] >= thr && !(have_m && __float_as_uint(acc[r]) == mb)) append_bits(__float_as_uint(acc[r]), base);
             cmax += 16;
         }
         if (cmax > CAP - 1) make_room(1);

@@ -92,6 +92,55 @@ def test_mfma_scan_matches_oracle_and_popcount(cs, kind, N, nq, k):
         assert torch.equal(dmm, dm) and torch.equal(imm, im)
 
 
+@pytest.mark.parametrize("cs,k", [(32, 11), (64, 11), (64, 5), (32, 12), (16, 11), (64, 20)])
+def test_columns_that_fill_up_during_the_sweep(cs, k):
+    """The lane-private candidate columns hold k + 16 keys.  Random data never fills one (a lane sees ~3 candidates per
+    sweep), so the in-sweep compaction -- bisection for the k-th smallest distance, keep everything up to it, tighten the
+    lane's threshold; the serial exact selection when ties fill the column -- needs data built for it: a table whose first
+    fifth is far from the queries (loose bound from the sample) and whose rest holds, for a few queries, long runs of
+    near-duplicates (a) at pairwise different distances, (b) all at the same distance (ties by id), (c) packed into single
+    tiles (many passing rows of one lane in one tile: the walk path with a column that is already nearly full).  Every
+    list must equal the popcount kernel's and the C oracle's."""
+    from oracle import c_oracle as co
+    from pinsage_hip import dense
+    rs = np.random.RandomState(cs * 100 + k)
+    N, nq, nbits = 16384, 96, cs * 8
+    codes = rs.randint(0, 256, size=(N, cs)).astype(np.uint8)
+    q = rs.randint(0, 256, size=(nq, cs)).astype(np.uint8)
+
+    def flipped(base, nflip):
+        c = base.copy()
+        for b in rs.choice(nbits, size=nflip, replace=False):
+            c[b >> 3] ^= np.uint8(1 << (b & 7))
+        return c
+
+    first = N // 5 + 64                                           # beyond the bound pass's sample
+    # (a) query 0: 120 near-duplicates at distances 1..60 (two each), all in rows = 5 mod 32 (one lane's rows) of the later tiles
+    rows = first + 5 + 32 * np.arange(120)
+    for j, r in enumerate(rows):
+        codes[r] = flipped(q[0], 1 + j // 2)
+    # (b) query 1: 200 copies at distance exactly 3 (ties: ids decide), rows = 9 mod 32
+    rows = first + 9 + 32 * np.arange(200)
+    for r in rows:
+        codes[r] = flipped(q[1], 3)
+    # (c) query 2: whole tiles of near-duplicates (32 consecutive rows, distances 1..8), six tiles apart, 12 of them
+    for t in range(12):
+        r0 = (first // 32 + 3 + 6 * t) * 32
+        for j in range(32):
+            codes[r0 + j] = flipped(q[2], 1 + (j % 8))
+    # (d) query 3: 40 exact duplicates scattered over every lane
+    for r in rs.choice(np.arange(first, N), size=40, replace=False):
+        codes[r] = q[3]
+    ct, qt = torch.from_numpy(codes).cuda(), torch.from_numpy(q).cuda()
+    assert dense.hamming_mfma_supported(nq, N, cs, k)
+    dm, im = dense.hamming_topk(qt, ct, k, planes=dense.lsh_expand(ct))
+    dv, iv = dense.hamming_topk(qt, ct, k, use_mfma=False)
+    assert torch.equal(dm, dv) and torch.equal(im, iv)
+    rd, ri = co.hamming_topk(q, codes, k, threads=8)
+    assert np.array_equal(im.cpu().numpy(), ri) and np.array_equal(dm.cpu().numpy().astype(np.float32), rd)
+    assert int(dm[3, 0]) == 0 and int(dm[1, k - 1]) == 3 and int(dm[0, 0]) == 1
+
+
 def test_mfma_unsupported_shapes_fall_back():
     """k > 32, small tables and few queries are served by the popcount kernel; the wrapper must say so, not fail"""
     from pinsage_hip import dense

@@ -16,12 +16,7 @@ L = native.lib()
 for _ in range(20):
     dense.hamming_topk(q, codes, k, planes=planes)
 torch.cuda.synchronize()
-import ctypes as _C
-_sym = _C.c_void_p()
-# the stamps of the LAST launch only: clear, then one more launch
-_hip = _C.CDLL("libamdhip64.so")
-zero = (_C.c_ulonglong * 16384)()
-L.ps_debug_hm_times_clear()
+L.ps_debug_hm_times_clear()                     # the stamps of ONE launch: clear, then one more launch
 dense.hamming_topk(q, codes, k, planes=planes)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 16384)()
