@@ -88,6 +88,52 @@ def test_importance_pooling_list_api_golden(golden):
         np.testing.assert_allclose(out.cpu().numpy(), g[f"g2_out_{tag}"], rtol=RTOL, atol=ATOL)
 
 
+def test_importance_pool_shape_fuzz_both_kernels(monkeypatch):
+    """ps_importance_pool over shapes around its kernels' boundaries -- T = 1 / 16 / 17 / 50 / 64 (four-rows-per-wave kernel with one
+    and four 16-entry pages) and 65 / 100 (one wave per row), H below, at and beyond one 256-column sweep and not a multiple of
+    it, visit counts or given fp32 weights, with and without renormalisation, ids that are dropped (beyond max_idx, negative),
+    rows with nothing kept, a row count that is not a multiple of four -- against an fp64 restatement of
+    ImportancePooling.forward (model/pinsage.py:101-150), and the two kernels against each other."""
+    from pinsage_hip import sampling
+    rs = np.random.RandomState(11)
+    for T, H, B, N in [(1, 32, 7, 50), (10, 256, 1001, 400), (16, 260, 130, 90), (17, 100, 66, 300), (50, 256, 513, 2000),
+                       (64, 512, 65, 70), (65, 64, 40, 60), (100, 256, 33, 500), (10, 4, 9, 12)]:
+        x = rs.standard_normal((N, H)).astype(np.float32)
+        ids = rs.randint(-1, N + N // 3 + 1, size=(B, T)).astype(np.int32)          # some beyond max_idx, some negative
+        nvalid = rs.randint(0, T + 1, size=B).astype(np.int32)
+        nvalid[rs.randint(0, B, size=max(1, B // 10))] = 0
+        counts = rs.randint(1, 30, size=(B, T)).astype(np.int32)
+        wts = (rs.random_sample((B, T)) + 0.05).astype(np.float32)
+        max_idx = N - 1 - rs.randint(0, 5)
+        xt, it, nt = torch.from_numpy(x).cuda(), torch.from_numpy(ids).cuda(), torch.from_numpy(nvalid).cuda()
+        for use_counts in (True, False):
+            for renorm in (True, False):
+                kw = dict(ids=it, counts=torch.from_numpy(counts).cuda() if use_counts else None,
+                          wts=None if use_counts else torch.from_numpy(wts).cuda(), nvalid=nt, max_idx=max_idx, renorm=renorm)
+                monkeypatch.delenv("PS_POOL_ROWS_PER_WAVE", raising=False)
+                a = sampling.importance_pool(xt, **kw).cpu().numpy()
+                monkeypatch.setenv("PS_POOL_ROWS_PER_WAVE", "1")
+                b = sampling.importance_pool(xt, **kw).cpu().numpy()
+                ref = np.zeros((B, H))
+                for i in range(B):
+                    k = int(nvalid[i])
+                    if use_counts:
+                        tot = counts[i, :k].sum()
+                        w = np.array([np.float32(np.float64(c) / np.float64(tot)) for c in counts[i, :k]], dtype=np.float32)
+                    else:
+                        w = wts[i, :k].copy()
+                    keep = (ids[i, :k] >= 0) & (ids[i, :k] <= max_idx)
+                    w = np.where(keep, w, np.float32(0))
+                    sw = np.float32(w.sum(dtype=np.float64))
+                    if renorm and sw > 0:
+                        w = w / sw
+                    ref[i] = (x[np.where(keep, ids[i, :k], 0)].astype(np.float64) * w[:, None].astype(np.float64)).sum(0)
+                np.testing.assert_allclose(a, ref, rtol=2e-5, atol=2e-6, err_msg=str((T, H, B, use_counts, renorm)))
+                np.testing.assert_allclose(b, ref, rtol=2e-5, atol=2e-6, err_msg=str((T, H, B, use_counts, renorm)))
+                if T <= 16:
+                    assert np.array_equal(a, b), (T, H, B, use_counts, renorm)          # the same operations in the same order
+
+
 def test_pool_backward_matches_torch():
     from model.pinsage import ImportancePooling
     torch.manual_seed(0)
