@@ -12,7 +12,8 @@
 // what the CPU oracle evaluates, so LSH sign decisions are bit-exact.
 //
 // Tiling: WM x WN waves; block tile BM x BN = (WM*TM*32) x (WN*TN*32): 64 x 256 when the epilogue normalises whole
-// rows, 64 x 128 otherwise, 32 x 256 for small shards; K step BK = 32 (BK = 16 was measured 6 % slower: the 64 x 256
+// rows, 64 x 128 otherwise, 32 x 256 for small shards (gemm_shard_kernel below when the launch is at most two workgroups per
+// CU); K step BK = 32 (BK = 16 was measured 6 % slower: the 64 x 256
 // tile is register limited to 2 waves per SIMD, not LDS limited).
 // LDS image per operand row: [BK/8 groups of 8 k][lane-half h][4] so that the lane (row i, half h)
 // fetches its four k values of one group (k = 8g + 2t + h, t = 0..3) with a single ds_read_b128;
@@ -24,6 +25,7 @@
 // the younger runs in its gaps; MFMA and VALU instructions do not overlap on a SIMD, which is what prices the epilogue
 // (tools/gemm_trace.py).
 #include "ps_common.h"
+#include <type_traits>
 
 #ifndef PS_GEMM_DEBUG
 #define PS_GEMM_DEBUG 0    // knock-out experiments (tools/gemm_knockout.sh): 1 no global fetch after the first K step, 2 no LDS
@@ -823,6 +825,195 @@ __global__ __launch_bounds__(DMA_WAVES * 64, 2) void gemm_dma_kernel(GemmArgs g)
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// gemm_shard_kernel: the GEMM of ONE SHARD of a multi-GPU job (59 047 items / 8 ranks = 7 381 rows) and of every other call
+// with so few rows that the launch is one or two workgroups per CU.  Such a launch is not bound by the matrix pipe but by the
+// serial step of its lone workgroup: gemm_f32_kernel's 32 x 256 tile spent 2 668 cycles in a K step's 32 MFMAs (2 048 of pipe
+// time), 936 in barrier / register -> LDS staging / barrier, and had nobody else on the CU to fill either gap (tools/gemm_trace.py
+// 7381 with PS_GEMM_PERSIST=0).  Here a K step is ONE barrier: both operands come into a ring of STAGES LDS images by
+// global_load_lds_dwordx4 (no staging registers, no ds_write), requested STAGES - 1 steps ahead with counted vmcnt, the first
+// fragments of a step are read before the next stage is requested, and a step's MFMA chain never waits for memory it did not
+// ask for a whole step earlier.  Tile 32 x 256, 4 waves of 32 x 64, v_mfma_f32_32x32x2_f32 with k ascending and one accumulator
+// per output: the same fmaf chain, bit for bit, as every other kernel of this file.
+// LDS image of a stage (36 one-KiB pieces, lane-linear for the DMA):
+//   piece j < 4      : x, lane = (row r = lane & 31, 16-byte chunk 2 j + (lane >> 5)) of the step's 128-byte row slab
+//   piece 4 + 8 rb + c: W rows rb * 64 + lane, chunk c
+// A lane (row i, k half h) of a natural-order operand takes the two floats h and 2 + h of a chunk (one ds_read2_b32: k = 4 c + h
+// and 4 c + 2 + h); of a weight stored in image order (PS_WPERM: k 0 2 4 6 | 1 3 5 7 per group of 8) it takes chunk 2 g + h whole
+// (one ds_read_b128 = its four k of the group).
+constexpr int SH_BM = 32, SH_BN = 256, SH_BK = 32;
+constexpr int SH_STAGE_BYTES = (SH_BM + SH_BN) * SH_BK * 4;              // 36 KiB
+constexpr int SH_TAIL_BYTES = (SH_BM * 4 + SH_BM * 4) * 4;               // sRed + sNrm of the epilogue
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void shard_lds_dma16(uint32_t voff, const void *sbase, uint32_t lds_byte_offset) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_offset) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+template <int EPI, bool WP, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_shard_kernel(GemmArgs g) {
+    static_assert(STAGES == 2 || STAGES == 3, "ring of two or three images");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv;                                       // 1 x 4 waves of 32 x 64 outputs
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * SH_BM;
+    const int n0 = blockIdx.y * SH_BN;
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(dsm);
+    const int nk1 = g.K / SH_BK, nk2 = (g.x2 ? g.K2 : 0) / SH_BK, nks = nk1 + nk2;
+    float *sRed = reinterpret_cast<float *>(dsm + STAGES * SH_STAGE_BYTES), *sNrm = sRed + SH_BM * 4;
+
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+
+    // this wave's nine pieces of a stage: piece wv of x, pieces 4 + wv + 4 (q - 1), q = 1..8, of W.  Per lane the byte offset of
+    // its 16 bytes from the tile's first row at k = 0 of the operand pair (rows past the end are clamped: never stored);
+    // a K step moves the scalar base only.
+    uint32_t voff[9];
+    auto offsets = [&](bool second) {
+        const int K = second ? g.K2 : g.K, ldw = second ? g.ldw2 : g.ldw;
+        int64_t row = m0 + li;
+        row = (row < g.M ? row : g.M - 1) - m0;
+        voff[0] = (uint32_t)row * (uint32_t)K * 4u + (uint32_t)(2 * wv + lh) * 16u;
+#pragma unroll
+        for (int q = 1; q < 9; ++q) {
+            const int idx = wv + 4 * (q - 1);                // wave-uniform
+            int n = n0 + (idx >> 3) * 64 + lane;
+            n = (n < g.N ? n : g.N - 1) - n0;
+            voff[q] = (uint32_t)n * (uint32_t)ldw * 4u + (uint32_t)(idx & 7) * 16u;
+        }
+    };
+    // scalar cursors: the tile's first row at the K step to request next, of the current operand pair
+    const float *Xc = g.x + m0 * g.K, *Wc = g.W + (int64_t)n0 * g.ldw;
+    const float *X2c = g.x2 ? g.x2 + m0 * g.K2 : nullptr, *W2c = g.x2 ? g.W2 + (int64_t)n0 * g.ldw2 : nullptr;
+    uint32_t issue_lds = 0;
+    auto issue_begin = [&](int ks, int buf) {
+        if (ks == nk1) {                                     // block-uniform: the contraction moves on to (x2, W2)
+            offsets(true);
+            Xc = X2c;
+            Wc = W2c;
+        }
+        issue_lds = lds_base + (uint32_t)(buf * SH_STAGE_BYTES + wv * 1024);
+    };
+    auto issue_piece = [&](int q) {                           // q = 0: this wave's piece of x; 1..8: its pieces of W
+        shard_lds_dma16(voff[q], q == 0 ? Xc : Wc, issue_lds + (uint32_t)q * 4096u);
+        if (q == 8) {
+            Xc += SH_BK;
+            Wc += SH_BK;
+        }
+    };
+    auto issue = [&](int ks, int buf) {
+        issue_begin(ks, buf);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) issue_piece(q);
+    };
+
+#if PS_GEMM_DEBUG & 64
+    // timeline (tools/gemm_shard_trace.py): sums kept in registers and stored after the loop -- a store inside it would
+    // join the vmcnt FIFO the counted waits rely on
+    const unsigned long long tr_start = __builtin_readcyclecounter();
+    unsigned long long tr_wait = 0, tr_first = 0, tr_stream = 0, tr_a = 0, tr_b = 0, tr_c = 0;
+#endif
+    offsets(false);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // nothing of the compiler's in flight (vmcnt(0), builtin form)
+    issue(0, 0);
+    if (STAGES == 3 && nks > 1) issue(1, 1);
+    int buf = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+#if PS_GEMM_DEBUG & 64
+        tr_a = __builtin_readcyclecounter();
+        if (ks > 0) tr_stream += tr_a - tr_c;
+#endif
+        // stage ks has landed -- this wave's pieces; behind the barrier everybody's -- and everybody is done with the image of
+        // stage ks - 1, which the request issued below overwrites
+        if (STAGES == 3 && ks + 1 < nks) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#if PS_GEMM_DEBUG & 64
+        tr_b = __builtin_readcyclecounter();
+        tr_wait += tr_b - tr_a;
+#endif
+        const unsigned char *sA = dsm + buf * SH_STAGE_BYTES + li * 16 + lh * 4;
+        const unsigned char *sB = dsm + buf * SH_STAGE_BYTES + (4 + wn * 8) * 1024 + li * 16 + (WP ? lh * 1024 : lh * 4);
+        float av[2][4];                                      // [slot parity][t]: k = 8 g + 2 t + lh
+        f32x4 bv[2][2];                                      // [slot parity][tile]: component t
+        auto frags = [&](int grp, int s) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float *p = reinterpret_cast<const float *>(sA + grp * 1024 + h * 512);
+                av[s][2 * h] = p[0];
+                av[s][2 * h + 1] = p[2];
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (WP) {
+                    bv[s][b] = *reinterpret_cast<const f32x4 *>(sB + 2 * grp * 1024 + b * 512);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float *p = reinterpret_cast<const float *>(sB + (2 * grp + h) * 1024 + b * 512);
+                        bv[s][b][2 * h] = p[0];
+                        bv[s][b][2 * h + 1] = p[2];
+                    }
+                }
+            }
+        };
+        // Issue order of the step, pinned (sched_barrier): the first group's fragments, then per group the next group's
+        // fragments, and the nine requests of the stage STAGES - 1 steps ahead one at a time behind the step's first nine MFMAs --
+        // issued in one burst behind the barrier they kept the matrix pipe idle for ~500 cycles of every step
+        // (tools/gemm_shard_trace.py: barrier -> first fragments 687 cycles per step, 2 048 of MFMA)
+        const int nx = ks + STAGES - 1;
+        frags(0, 0);
+        auto stream = [&](auto more_tag) __attribute__((always_inline)) {
+            constexpr bool MORE = decltype(more_tag)::value;
+            if (MORE) issue_begin(nx, buf == 0 ? STAGES - 1 : buf - 1);   // (buf + STAGES - 1) % STAGES: the image of stage ks - 1
+            __builtin_amdgcn_sched_barrier(0);
+#if PS_GEMM_DEBUG & 64
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the step's first fragments are here
+            tr_c = __builtin_readcyclecounter();
+            tr_first += tr_c - tr_b;
+#endif
+#pragma unroll
+            for (int grp = 0; grp < SH_BK / 8; ++grp) {
+                const int s = grp & 1;
+                if (grp + 1 < SH_BK / 8) {
+                    frags(grp + 1, s ^ 1);                       // next group's fragments before this group's MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][t], bv[s][b][t], acc[0][b], 0, 0, 0);
+                        const int q = grp * 8 + t * 2 + b;
+                        if (MORE && q < 9) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_piece(q);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            }
+        };
+        if (nx < nks) stream(std::true_type{});              // block-uniform
+        else stream(std::false_type{});
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+    }
+#if PS_GEMM_DEBUG & 64
+    if (lane == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+        unsigned long long *t = ps_gemm_trace_buf + ((size_t)blockIdx.x * 4 + wv) * 48;
+        t[0] = tr_start; t[1] = tr_wait; t[2] = tr_first; t[3] = tr_stream + (__builtin_readcyclecounter() - tr_c);
+        t[46] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4); t[47] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);
+    }
+#endif
+    gemm_epilogue<1, 4, 1, 2, EPI>(g, acc, m0, n0, sRed, sNrm);
+}
+
 __global__ void l2norm_rows_kernel(float *y, int64_t M, int N) {   // N > 256 only
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -923,10 +1114,49 @@ bool aligned_operand(const float *p, int K, int ld) {
     return p == nullptr || (reinterpret_cast<size_t>(p) % 16 == 0 && K % 32 == 0 && ld % 4 == 0);
 }
 
+template <int EPI, bool WP, int STAGES>
+int launch_shard(const GemmArgs &g, hipStream_t st) {
+    constexpr int lds = STAGES * SH_STAGE_BYTES + SH_TAIL_BYTES;
+    static PsPerDevice attr_done;                             // per instantiation
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PS_ELAUNCH;
+    if (!attr_done.get(devid)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_shard_kernel<EPI, WP, STAGES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return PS_ELAUNCH;
+        attr_done.set(devid, 1);
+    }
+    dim3 grid((unsigned)ps_cdiv(g.M, SH_BM), (unsigned)ps_cdiv(g.N, SH_BN));
+    hipLaunchKernelGGL((gemm_shard_kernel<EPI, WP, STAGES>), grid, dim3(256), lds, st, g);
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
+// Which launches go to gemm_shard_kernel (measured r04 on 7 381 / 14 762-row shards, tools/gemm_probe.py --env PS_GEMM_SHARD=0,2,3,
+// image-order weights): the layer GEMM (K = 256 + 256, fused norm) 30.3 -> 26.9 us with the ring of three at 231 tiles and
+// 48.2 -> 45.8 us with the ring of two at 462, the output projection (K = 256, fused norm) 18.3 -> 17.1 / 26.4 -> 26.0; launches
+// WITHOUT the whole-row epilogue are no faster than the 64 x 128 tiles they already use (input projection 11.3 vs 11.1 us,
+// LSH projection 23.4 vs 23.3 at 7 381 rows and 39.9 vs 46.6 at 14 762) and stay there.
+constexpr int64_t SHARD_TILES_RING3 = 256, SHARD_TILES_RING2 = 512;
+
 template <int EPI>
 int launch_gemm(const GemmArgs &g, hipStream_t st) {
     const bool fast = aligned_operand(g.x, g.K, g.K) && aligned_operand(g.W, g.K, g.ldw) &&
                       (g.x2 == nullptr || (aligned_operand(g.x2, g.K2, g.K2) && aligned_operand(g.W2, g.K2, g.ldw2)));
+    {
+        // PS_GEMM_SHARD: 0 = never, 2 / 3 = that ring depth whenever the operands allow (tests, experiments); default: by size
+        const char *se = getenv("PS_GEMM_SHARD");
+        const int mode = se ? atoi(se) : -1;
+        const int64_t tiles = ps_cdiv(g.M, SH_BM) * ps_cdiv(g.N, SH_BN);
+        const bool fits = (int64_t)g.ldw * 1024 < 0x7fffffff && (g.x2 == nullptr || (int64_t)g.ldw2 * 1024 < 0x7fffffff) &&
+                          (int64_t)g.K * 128 < 0x7fffffff && (g.x2 == nullptr || (int64_t)g.K2 * 128 < 0x7fffffff);
+        const bool by_size = EPI == 0 && (g.flags & PS_L2NORM) && tiles <= SHARD_TILES_RING2;
+        if (fast && fits && g.grp == nullptr && g.N > 128 && mode != 0 && (mode > 0 || by_size)) {
+            const bool wp = (g.flags & PS_WPERM) != 0;
+            if (mode == 3 || (mode < 0 && tiles <= SHARD_TILES_RING3))
+                return wp ? launch_shard<EPI, true, 3>(g, st) : launch_shard<EPI, false, 3>(g, st);
+            return wp ? launch_shard<EPI, true, 2>(g, st) : launch_shard<EPI, false, 2>(g, st);
+        }
+    }
     // LDS-DMA kernel (opt-in, PS_GEMM_DMA=1: measured SLOWER than gemm_f32_kernel on MI355X, 82 vs 87.5 TFLOP/s for the
     // layer GEMMs and 85 vs 94 for the LSH projection -- one barrier per K step and no staging registers do not pay for
     // the doubled fragment reads, the lane-half selects and the 16-bytes-per-row DMA pieces; kept because it is tested

@@ -621,6 +621,41 @@ def test_dma_gemm_is_bit_identical_to_the_register_staged_gemm(M, K, N, K2, relu
     assert torch.equal(c_dma, c_reg)
 
 
+@pytest.mark.parametrize("M,K,N,K2,relu,l2", [(7381, 256, 256, 256, True, True), (7381, 128, 256, 0, True, False),
+                                              (7381, 256, 256, 0, False, True), (2500, 64, 512, 32, False, False),
+                                              (33, 32, 129, 96, True, True), (1, 256, 256, 256, True, True),
+                                              (16384, 96, 200, 160, False, True)])
+def test_shard_gemm_is_bit_identical_to_the_register_staged_gemm(M, K, N, K2, relu, l2, monkeypatch):
+    """gemm_shard_kernel (small launches: both operands through LDS-DMA into a ring of two or three images, one barrier per K step)
+    vs gemm_f32_kernel / gemm_f32_pkernel (PS_GEMM_SHARD=0), which test_linear_vs_oracle holds to the fmaf-chain oracle: the
+    same MFMA, k order and epilogue, so the outputs must be BIT-identical -- for ps_linear and for the LSH sign pack, plain and
+    image-order weights (views with a row stride of K + K2), both ring depths, ragged last tiles in both dimensions, K != K2."""
+    from pinsage_hip import dense
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K + K2, generator=g) / (K + K2) ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    x2 = torch.randn(M, K2, generator=g).cuda() if K2 else None
+    W1, W2 = W[:, :K], (W[:, K:] if K2 else None)
+    A = torch.randn(512 if N > 256 else 256, K, generator=g).cuda()
+
+    def run():
+        out = [dense.lsh_encode(x, A), dense.lsh_encode(x, dense.stage_weight(A))]
+        if N <= 256 or not l2:
+            out.append(dense.linear(x, W1, b, x2=x2, W2=W2, relu=relu, l2norm=l2))
+            out.append(dense.linear(x, dense.stage_weight(W1), b, x2=x2, W2=dense.stage_weight(W2) if K2 else None, relu=relu, l2norm=l2))
+        return out
+    monkeypatch.setenv("PS_GEMM_SHARD", "0")
+    ref = run()
+    for depth in ("2", "3"):
+        monkeypatch.setenv("PS_GEMM_SHARD", depth)
+        for r, y in zip(ref, run()):
+            assert torch.equal(r, y), depth
+    monkeypatch.delenv("PS_GEMM_SHARD")
+    for r, y in zip(ref, run()):                                   # the launcher's own choice
+        assert torch.equal(r, y)
+
+
 @pytest.mark.parametrize("M,N", [(70, 256), (25000, 256), (90, 128), (50, 64)])
 def test_fused_norm_quotient_is_the_ieee_division(M, N):
     """The fused row-normalise epilogue (csrc/dense_mfma.hip) divides by fma corrections of x * RN(1/norm) on its fast path

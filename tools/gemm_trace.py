@@ -12,7 +12,7 @@ from pinsage_hip import dense, native
 
 lib = native.lib() if hasattr(native, "lib") else ctypes.CDLL(os.environ["PS_HIP_LIB"])
 raw = ctypes.CDLL(os.environ["PS_HIP_LIB"])
-M, K, N = 59047, 256, 256
+M, K, N = (int(sys.argv[1]) if len(sys.argv) > 1 else 59047), 256, 256    # 7381 + PS_GEMM_PERSIST=0: the 32 x 256 shard tile
 dev = torch.device("cuda")
 x = torch.randn(M, K, device=dev); x2 = torch.randn(M, K, device=dev)
 W = torch.randn(N, K, device=dev) / 16; W2 = torch.randn(N, K, device=dev) / 16; b = torch.randn(N, device=dev)
