@@ -330,7 +330,7 @@ def main():
             add("ps_lsh_encode", "mfma", enc_flops * rows, MFMA_F32_PEAK)
         # Hamming scan as an exact +-1 contraction on fp4 MFMA: 2 * nq * N * nbits sign operations (dot = nbits - 2 *
         # hamming); the C-ABI call covers the bound pass (1/5 of the table again), the collect pass and the slice merge
-        add("ps_hamming_topk_mfma", "mfma", 2.0 * nq * n_loc * nbits, MFMA_FP4_PEAK)
+        add("ps_hamming_topk_mfma_codes", "mfma", 2.0 * nq * n_loc * nbits, MFMA_FP4_PEAK)
         # popcount fallback (shapes the MFMA path does not serve): VALU bound on the logical code bytes
         add("ps_hamming_topk", "valu", float(nq) * n_loc * (nbits // 8), VALU_POPCNT_PEAK)
         for mt_call in ("ps_mt19937_raw_stream", "ps_mt19937_random_sample"):     # numpy-stream mode: 8 B written per uniform
@@ -346,7 +346,7 @@ def main():
             traffic = {}
         for n, k in kern.items():
             if k.get("bound") == "mfma":
-                meas = MFMA_FP4_MEASURED if n == "ps_hamming_topk_mfma" else MFMA_F32_MEASURED
+                meas = MFMA_FP4_MEASURED if n == "ps_hamming_topk_mfma_codes" else MFMA_F32_MEASURED
                 k["frac_of_measured_mfma_rate"] = k["achieved"] / meas
             if isinstance(traffic.get(n), (int, float)) and traffic[n] > 0:
                 k["counter_bytes_per_launch"] = traffic[n]
@@ -372,7 +372,7 @@ def main():
         kd = kern[dom]
         div = 1e9 if kd["bound"] in ("hbm", "valu", "mall") else 1e12
         unit = {"hbm": "GB/s", "valu": "GB/s", "mall": "GB/s", "mfma": "TFLOP/s"}[kd["bound"]]
-        if dom == "ps_hamming_topk_mfma":
+        if dom == "ps_hamming_topk_mfma_codes":
             unit = "TOP/s"
         roofline = {"kernel": dom, "dominant_kernel": dominant_call,
                     "dominant_kernel_ms_per_step": kern[dominant_call]["ms_per_step"], "dominant_bound": kern[dominant_call]["bound"],
@@ -381,7 +381,7 @@ def main():
                     "unit": unit, "frac": kd["frac"],
                     "traffic": traffic.get(dom), "traffic_source": traffic.get("source") if dom in traffic else None,
                     "avg_launch_ms": kd["avg_ms"], "algorithmic_per_launch": kd["achieved"] * kd["avg_ms"] * 1e-3,
-                    "note": {"ps_hamming_topk_mfma": "exact +-1 contraction on fp4 MFMA; peak = dense fp4 (4 x bf16 per clock at 2.4 GHz); "
+                    "note": {"ps_hamming_topk_mfma_codes": "exact +-1 contraction on fp4 MFMA; peak = dense fp4 (4 x bf16 per clock at 2.4 GHz); "
                                                      "the call includes the bound pass over 1/5 of the table, counted as overhead",
                              "ps_walk_sample_layers": "algorithmic bytes per SURVEY 8(d) (8 B row bounds + 8 B x ceil(log2(deg+1)) CDF "
                                                       "probes + 4 B col [+ 8 B uniform] per taken step, T x 8 + 4 B out per start "
@@ -394,7 +394,7 @@ def main():
                    "ps_linear": ["gemm_f32_pkernel<2,2,1,2,32,0> (input_proj: no row norm, 64x128 tiles, persistent)",
                                  "gemm_f32_kernel<1,4,2,2,32,0,true> (layers + output_proj: fused L2 norm, 64x256 tiles)"],
                    "ps_lsh_encode": ["gemm_f32_pkernel<2,2,1,2,32,1>"],
-                   "ps_hamming_topk_mfma": ["hamming_pipe_kernel<KS, 0> (bound)", "bound_select_kernel",
+                   "ps_hamming_topk_mfma_codes": ["hamming_pipe_kernel<KS, 0> (bound)", "bound_select_kernel",
                                             "hamming_pipe_kernel<KS, 1> (collect)", "slice_merge_kernel"],
                    "ps_hamming_topk": ["hamming_scan_kernel<16,4>", "topk_rank_merge_kernel"],
                    "ps_mt19937_raw_stream": ["mt_begin", "mt_planes", "mt_jump_mfma", "mt_jump_reduce", "mt_jump_finish", "mt_chunk (both directions)"],
@@ -415,8 +415,8 @@ def main():
             k["achieved"] = k["achieved"] / div
             k["peak"] = k["peak"] / div
             k["unit"] = "TFLOP/s" if k["bound"] == "mfma" else "GB/s"
-        if "ps_hamming_topk_mfma" in kern:
-            kern["ps_hamming_topk_mfma"]["unit"] = "TOP/s"
+        if "ps_hamming_topk_mfma_codes" in kern:
+            kern["ps_hamming_topk_mfma_codes"]["unit"] = "TOP/s"
 
         out = {
             "metric": "item embeddings/sec + top-K ANN queries/sec, ML-25M d=256, 1/2/4/8 GPU",

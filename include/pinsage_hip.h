@@ -234,6 +234,10 @@ int ps_hamming_topk(const uint8_t *qcodes, int64_t nq, const uint8_t *codes, int
  *   ps_lsh_planes_bytes(n, cs)      : size of the plane table of n codes = 4 x the packed codes (0 if cs % 8 != 0)
  *   ps_lsh_expand(codes, n, cs, pl) : builds it (16-B aligned); done at LSHIndex.build time for the table, per call
  *                                     for the queries
+ *   ps_hamming_topk_mfma_codes      : the same search with the QUERIES given as packed codes (4-B aligned, cs bytes each):
+ *                                     every workgroup of the scan expands its own 32 queries in registers, which saves
+ *                                     the ps_lsh_expand launch in front of a search (the table's planes are still built
+ *                                     once per index)
  *   ps_hamming_topk_mfma_workspace_bytes : 0 when the shape is not served (k > 32, code size not 8 / 16 / 32 / 64 bytes,
  *                                     fewer than 64 queries or 4096 items): callers use ps_hamming_topk then;
  *                                     ps_hamming_topk_mfma itself returns PS_EUNSUPPORTED for such shapes. */
@@ -243,6 +247,9 @@ size_t ps_hamming_topk_mfma_workspace_bytes(int64_t nq, int64_t N, int cs, int k
 int ps_hamming_topk_mfma(const void *qplanes, int64_t nq, const void *dbplanes, int64_t N, int cs, int k,
                          int64_t id_offset, int32_t *dist, int64_t *ids,
                          void *workspace, size_t workspace_bytes, ps_stream_t stream);
+int ps_hamming_topk_mfma_codes(const uint8_t *qcodes, int64_t nq, const void *dbplanes, int64_t N, int cs, int k,
+                               int64_t id_offset, int32_t *dist, int64_t *ids,
+                               void *workspace, size_t workspace_bytes, ps_stream_t stream);
 
 /* Merge P sorted candidate lists per query (multi-GPU shards: all-gathered [P, nq, k]) into the
  * global k best by (distance, id). */

@@ -90,6 +90,14 @@ constexpr float NO_DOT = -1048576.0f;       // "no item": below every real dot (
 template <int KS> struct EntryTiles { static constexpr int value = KS >= 4 ? 2 : 4; };
 
 // ---- sign planes ------------------------------------------------------------------------------------------------
+// 32 code bits -> 32 fp4 nibbles: bit b -> +1 (0x2) / -1 (0xA) = 0xA ^ (b << 3); four bits are spread to the nibble positions
+// 0, 4, 8, 12 by OR-ing shifted copies (a multiply would carry between the overlapping copies)
+__device__ __forceinline__ uint4 expand_word(uint32_t bits) {
+    auto four = [](uint32_t n) { return (n | (n << 3) | (n << 6) | (n << 9)) & 0x1111u; };
+    auto eight = [&](uint32_t byte) { return 0xaaaaaaaau ^ ((four(byte & 15u) | (four(byte >> 4) << 16)) << 3); };
+    return make_uint4(eight(bits & 255u), eight((bits >> 8) & 255u), eight((bits >> 16) & 255u), eight(bits >> 24));
+}
+
 // one thread = one 16-byte piece (tile, step, lane): the 32 code bits of word 2 s + (lane >> 5) as 32 fp4 nibbles
 __global__ __launch_bounds__(256) void lsh_expand_kernel(const uint32_t *__restrict__ codes, int64_t n, int KS,
                                                          int64_t pieces, uint4 *__restrict__ planes) {
@@ -100,20 +108,14 @@ __global__ __launch_bounds__(256) void lsh_expand_kernel(const uint32_t *__restr
         const int64_t tile = ts / KS;
         const int64_t row = tile * 32 + (lane & 31);
         uint4 o = make_uint4(0u, 0u, 0u, 0u);
-        if (row < n) {
-            const uint32_t bits = codes[row * (2 * KS) + 2 * s + (lane >> 5)];
-            // 8 bits -> 8 nibbles: bit b -> +1 (0x2) / -1 (0xA) = 0xA ^ (b << 3); four bits are spread to the nibble
-            // positions 0, 4, 8, 12 by OR-ing shifted copies (a multiply would carry between the overlapping copies)
-            auto four = [](uint32_t n) { return (n | (n << 3) | (n << 6) | (n << 9)) & 0x1111u; };
-            auto eight = [&](uint32_t byte) { return 0xaaaaaaaau ^ ((four(byte & 15u) | (four(byte >> 4) << 16)) << 3); };
-            o.x = eight(bits & 255u); o.y = eight((bits >> 8) & 255u); o.z = eight((bits >> 16) & 255u); o.w = eight(bits >> 24);
-        }
+        if (row < n) o = expand_word(codes[row * (2 * KS) + 2 * s + (lane >> 5)]);
         planes[p] = o;
     }
 }
 
 struct HArgs {
-    const unsigned char *qplanes;
+    const unsigned char *qplanes;   // the queries' sign planes, or
+    const uint32_t *qcodes;         // (qplanes == nullptr) their packed codes: a workgroup expands its own 32 queries (query_frag)
     const unsigned char *dbplanes;
     int64_t nq, N;
     int64_t tile_begin, tile_end;   // tiles swept by this launch
@@ -128,6 +130,18 @@ struct HArgs {
     int32_t *out_d;                 // collect: [slices][nq][k] distances / table rows (-1 = none), ascending
     int32_t *out_r;
 };
+
+// The 16 bytes lane `lane` feeds to the MFMA for K step s of query tile qtile: read from the plane table, or -- packed query codes
+// -- built here (~40 integer instructions per step, once per workgroup, against a sweep of hundreds of tiles; saves the
+// ps_lsh_expand launch in front of every search)
+template <int KS>
+__device__ __forceinline__ v4i query_frag(const HArgs &a, int64_t qtile, int s, int lane) {
+    if (a.qplanes != nullptr) return *reinterpret_cast<const v4i *>(a.qplanes + ((qtile * KS + s) * 64 + lane) * 16);
+    const int64_t q = qtile * 32 + (lane & 31);
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);                   // rows past the end: zero nibbles, as in a padded plane table
+    if (q < a.nq) o = expand_word(a.qcodes[q * (2 * KS) + 2 * s + (lane >> 5)]);
+    return v4i{(int)o.x, (int)o.y, (int)o.z, (int)o.w};
+}
 
 // LDS-DMA issued from inline asm: hipcc (ROCm 7.2) cannot prove that a ds_read of ring buffer i does not alias the
 // global_load_lds into buffer i+2 and drains vmcnt(0) before every tile's first fragment read when the builtin is
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(512, DB ? 2 : 4) void hamming_mfma_kernel(HArgs a) 
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         bq[s] = v4i{0, 0, 0, 0};
-        if (qtile < nqtiles)
+        if (qtile < nqtiles)                                 // (packed query codes: the launcher expands them first, launch_passes)
             bq[s] = *reinterpret_cast<const v4i *>(a.qplanes + ((qtile * KS + s) * 64 + lane) * 16);
     }
 
@@ -558,7 +572,7 @@ __global__ __launch_bounds__(512, 4) void hamming_pipe_kernel(HArgs a) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         bq[s] = v4i{0, 0, 0, 0};
-        if (qtile < nqtiles) bq[s] = *reinterpret_cast<const v4i *>(a.qplanes + ((qtile * KS + s) * 64 + lane) * 16);
+        if (qtile < nqtiles) bq[s] = query_frag<KS>(a, qtile, s, lane);
     }
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
     const bool loader = wv < KS;                            // waves 0 .. KS - 1 bring in one 1 KiB piece of every tile
@@ -1094,7 +1108,7 @@ struct Plan {
     int KS, IT, nqb, slices, bslices, shift, km, cap;
     bool db;                // collect pass: one workgroup per CU with two fragment sets (any k) or two per CU (k <= 12)
     int64_t tiles, tiles_per_slice, sample_tiles, btiles_per_slice;
-    size_t off_thr, off_bl, off_i, off_d, total;
+    size_t off_thr, off_bl, off_i, off_d, off_qp, total;
 };
 
 int env_int(const char *name, int dflt) {
@@ -1157,6 +1171,7 @@ Plan make_plan(int64_t nq, int64_t N, int cs, int k) {
     p.off_bl = take((size_t)nq * p.bslices * 2 * p.km * sizeof(int32_t));
     p.off_i = take((size_t)p.slices * nq * k * sizeof(int32_t));
     p.off_d = take((size_t)p.slices * nq * k * sizeof(int32_t));
+    p.off_qp = take(ps_lsh_planes_bytes(nq, cs));          // query planes, when packed query codes meet a kernel that reads planes
     p.total = off + 256;
     p.ok = true;
     return p;
@@ -1170,7 +1185,7 @@ bool allow_lds(K kernel, size_t bytes) {
 }
 
 template <int KS>
-int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t *bl, int64_t nq) {
+int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t *bl, int64_t nq, void *qp_ws) {
     constexpr int IT = EntryTiles<KS>::value;
     constexpr int IT1 = KS >= 8 ? 1 : KS == 4 ? 2 : 4;      // entry of the two-workgroups-per-CU collect kernel
     const size_t tiles_lds = (size_t)NBUF * IT * KS * 1024;
@@ -1203,6 +1218,19 @@ int launch_passes(const Plan &p, HArgs a, hipStream_t st, int32_t *thr0, int32_t
     bool launched = false;
     // 0: the r03 kernels (cross-check / experiments); the pipelined kernels' keys hold a 17-bit tile index per slice
     const bool pipe = PipeServed<KS>::value && env_int("PS_HAMMING_PIPE", 1) != 0 && p.tiles_per_slice <= (1 << 17) && p.btiles_per_slice <= (1 << 17);
+    // packed query codes are expanded by the pipelined kernels' workgroups themselves; when either pass runs a kernel that reads
+    // planes (k > 12, 64- / 128-bit codes, PS_HAMMING_PIPE=0) the launcher builds them in the workspace first
+    if (a.qplanes == nullptr && !(pipe && !p.db && p.km == 4)) {
+        const int64_t pieces = (((nq + 31) / 32 + PAD_TILES - 1) / PAD_TILES * PAD_TILES) * KS * 64;
+        int64_t ge = ps_cdiv(pieces, 256);
+        if (ge > 256 * 64) ge = 256 * 64;
+        hipLaunchKernelGGL(lsh_expand_kernel, dim3((unsigned)ge), dim3(256), 0, st, a.qcodes, nq, KS, pieces, reinterpret_cast<uint4 *>(qp_ws));
+        PS_CHECK_LAUNCH();
+        a.qplanes = reinterpret_cast<const unsigned char *>(qp_ws);
+        a.qcodes = nullptr;
+        b.qplanes = a.qplanes;
+        b.qcodes = nullptr;
+    }
     if constexpr (PipeServed<KS>::value) {
         if (p.km == 4 && !p.db && pipe) {
             hipLaunchKernelGGL((hamming_pipe_kernel<KS, 0>), dim3(gb), dim3(512), (size_t)PipeRing<KS>::value * KS * 1024, st, b);
@@ -1279,14 +1307,15 @@ extern "C" size_t ps_hamming_topk_mfma_workspace_bytes(int64_t nq, int64_t N, in
     return p.ok ? p.total : 0;                                // 0 = shape not served by the MFMA path
 }
 
-extern "C" int ps_hamming_topk_mfma(const void *qplanes, int64_t nq, const void *dbplanes, int64_t N, int cs, int k,
-                                    int64_t id_offset, int32_t *dist, int64_t *ids, void *workspace,
-                                    size_t workspace_bytes, ps_stream_t stream) {
+static int hamming_topk_mfma(const void *qplanes, const uint8_t *qcodes, int64_t nq, const void *dbplanes, int64_t N, int cs, int k,
+                             int64_t id_offset, int32_t *dist, int64_t *ids, void *workspace, size_t workspace_bytes,
+                             ps_stream_t stream) {
     if (nq < 0 || N < 0 || cs <= 0 || k <= 0) return PS_EINVAL;
     const Plan p = make_plan(nq, N, cs, k);
     if (!p.ok) return PS_EUNSUPPORTED;
-    if (!qplanes || !dbplanes || !dist || !ids) return PS_EINVAL;
+    if ((!qplanes && !qcodes) || !dbplanes || !dist || !ids) return PS_EINVAL;
     if ((reinterpret_cast<size_t>(qplanes) | reinterpret_cast<size_t>(dbplanes)) % 16 != 0) return PS_EINVAL;
+    if (reinterpret_cast<size_t>(qcodes) % 4 != 0) return PS_EINVAL;
     if (!workspace || workspace_bytes < p.total) return PS_EWORKSPACE;
     char *base = reinterpret_cast<char *>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
     int32_t *thr0 = reinterpret_cast<int32_t *>(base + p.off_thr);
@@ -1296,16 +1325,17 @@ extern "C" int ps_hamming_topk_mfma(const void *qplanes, int64_t nq, const void 
     hipStream_t st = ps_stream(stream);
     HArgs a{};
     a.qplanes = reinterpret_cast<const unsigned char *>(qplanes);
+    a.qcodes = qplanes ? nullptr : reinterpret_cast<const uint32_t *>(qcodes);
     a.dbplanes = reinterpret_cast<const unsigned char *>(dbplanes);
     if (N >= ((int64_t)1 << 31)) return PS_EUNSUPPORTED;     // table rows travel as int32 between the passes
     a.nq = nq; a.N = N; a.k = k; a.nbits = cs * 8; a.shift = p.shift; a.id_offset = id_offset;
     a.out_d = cd; a.out_r = cr;
     int rc;
     switch (p.KS) {
-        case 1: rc = launch_passes<1>(p, a, st, thr0, bl, nq); break;
-        case 2: rc = launch_passes<2>(p, a, st, thr0, bl, nq); break;
-        case 4: rc = launch_passes<4>(p, a, st, thr0, bl, nq); break;
-        case 8: rc = launch_passes<8>(p, a, st, thr0, bl, nq); break;
+        case 1: rc = launch_passes<1>(p, a, st, thr0, bl, nq, base + p.off_qp); break;
+        case 2: rc = launch_passes<2>(p, a, st, thr0, bl, nq, base + p.off_qp); break;
+        case 4: rc = launch_passes<4>(p, a, st, thr0, bl, nq, base + p.off_qp); break;
+        case 8: rc = launch_passes<8>(p, a, st, thr0, bl, nq, base + p.off_qp); break;
         default: return PS_EUNSUPPORTED;
     }
     if (rc != PS_OK) return rc;
@@ -1317,4 +1347,18 @@ extern "C" int ps_hamming_topk_mfma(const void *qplanes, int64_t nq, const void 
                            dist, ids);
     PS_CHECK_LAUNCH();
     return PS_OK;
+}
+
+extern "C" int ps_hamming_topk_mfma(const void *qplanes, int64_t nq, const void *dbplanes, int64_t N, int cs, int k,
+                                    int64_t id_offset, int32_t *dist, int64_t *ids, void *workspace,
+                                    size_t workspace_bytes, ps_stream_t stream) {
+    if (!qplanes) return PS_EINVAL;
+    return hamming_topk_mfma(qplanes, nullptr, nq, dbplanes, N, cs, k, id_offset, dist, ids, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ps_hamming_topk_mfma_codes(const uint8_t *qcodes, int64_t nq, const void *dbplanes, int64_t N, int cs, int k,
+                                          int64_t id_offset, int32_t *dist, int64_t *ids, void *workspace,
+                                          size_t workspace_bytes, ps_stream_t stream) {
+    if (!qcodes) return PS_EINVAL;
+    return hamming_topk_mfma(nullptr, qcodes, nq, dbplanes, N, cs, k, id_offset, dist, ids, workspace, workspace_bytes, stream);
 }

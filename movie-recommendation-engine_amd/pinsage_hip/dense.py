@@ -171,10 +171,10 @@ def hamming_topk(qcodes, codes, k, id_offset=0, planes=None, use_mfma=True, out=
     if use_mfma and planes is not None:
         wsb = int(L.ps_hamming_topk_mfma_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(cs), nv.i32(k)))
         if wsb > 0:
-            qplanes = lsh_expand(qcodes)
             ws = torch.empty(wsb, dtype=torch.uint8, device=qcodes.device)
             with torch.cuda.device(qcodes.device):
-                nv.call("ps_hamming_topk_mfma", nv.ptr(qplanes), nv.i64(nq), nv.ptr(planes), nv.i64(N), nv.i32(cs),
+                # the queries go in as packed codes: the scan's workgroups build their own sign planes
+                nv.call("ps_hamming_topk_mfma_codes", nv.ptr(qcodes), nv.i64(nq), nv.ptr(planes), nv.i64(N), nv.i32(cs),
                         nv.i32(k), nv.i64(id_offset), nv.ptr(dist), nv.ptr(ids), nv.ptr(ws), nv.C.c_size_t(wsb),
                         nv.stream())
             return dist, ids

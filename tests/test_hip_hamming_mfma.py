@@ -1,4 +1,4 @@
-"""The MFMA Hamming scan (fp4 sign planes, csrc/hamming_mfma.hip: ps_lsh_expand + ps_hamming_topk_mfma) vs the C oracle's
+"""The MFMA Hamming scan (fp4 sign planes, csrc/hamming_mfma.hip: ps_lsh_expand + ps_hamming_topk_mfma / ps_hamming_topk_mfma_codes) vs the C oracle's
 restatement of faiss' hammings_knn_hc (reference utils/nearest_neighbors.py:47-68) and vs the popcount kernel:
 (distance, id) lists must be bit-identical -- same distances, same ids, same tie order, same padding.
 
@@ -227,3 +227,28 @@ def test_lsh_search_any_k(k):
     assert np.array_equal(i[:, :kk], ri + 1000) and np.array_equal(d[:, :kk].astype(np.float32), rd)
     if k > N:
         assert np.all(i[:, N:] == -1) and np.all(d[:, N:] == 0x7fffffff)
+
+
+@pytest.mark.parametrize("cs,N,nq,k", [(64, 9000, 300, 11), (32, 9000, 77 + 64, 10), (64, 5000, 100, 20), (16, 6000, 130, 9)])
+def test_query_planes_given_or_built_by_the_scan(cs, N, nq, k, monkeypatch):
+    """ps_hamming_topk_mfma (query sign planes made by ps_lsh_expand) and ps_hamming_topk_mfma_codes (packed query codes: the
+    pipelined kernels' workgroups expand their own 32 queries in registers -- 512- / 256-bit codes with k <= 12 -- and the launcher
+    expands into the workspace for every other kernel: k > 12, 128-bit codes, PS_HAMMING_PIPE=0) return the same lists, ragged
+    last query tile included."""
+    from pinsage_hip import dense, native as nv
+    rs = np.random.RandomState(cs + N + k)
+    codes = torch.from_numpy(_codes(rs, N, cs, "clustered")).cuda()
+    q = codes[torch.from_numpy(rs.permutation(N)[:nq]).cuda()].contiguous()
+    planes = dense.lsh_expand(codes)
+    qplanes = dense.lsh_expand(q)
+    wsb = int(nv.lib().ps_hamming_topk_mfma_workspace_bytes(nv.i64(nq), nv.i64(N), nv.i32(cs), nv.i32(k)))
+    assert wsb > 0
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    d0 = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    i0 = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    nv.call("ps_hamming_topk_mfma", nv.ptr(qplanes), nv.i64(nq), nv.ptr(planes), nv.i64(N), nv.i32(cs), nv.i32(k), nv.i64(5),
+            nv.ptr(d0), nv.ptr(i0), nv.ptr(ws), nv.C.c_size_t(wsb), nv.stream())
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("PS_HAMMING_PIPE", pipe)
+        d1, i1 = dense.hamming_topk(q, codes, k, id_offset=5, planes=planes)
+        assert torch.equal(d0, d1) and torch.equal(i0, i1), pipe

@@ -69,7 +69,7 @@ out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, ben
        # the same bench run launches the Philox one (listed in the .txt, not part of this figure)
        "ps_walk_sample": per_launch(_sampler_kernel),
        "ps_walk_sample_layers": per_launch(_sampler_kernel),
-       "ps_hamming_topk_mfma": per_launch(lambda k: k.startswith("hamming_mfma_kernel") or k.startswith("hamming_pipe_kernel") or k.startswith("bound_select_kernel")
+       "ps_hamming_topk_mfma_codes": per_launch(lambda k: k.startswith("hamming_mfma_kernel") or k.startswith("hamming_pipe_kernel") or k.startswith("bound_select_kernel")
                                           or k.startswith("slice_merge_kernel")),
        # every mt_* kernel of the one-round generator runs once per call (begin, planes, jump products, reduce, finish, chunks)
        "ps_mt19937_raw_stream": per_launch(lambda k: k.startswith("mt_") and not k.startswith("mt_raw_to_double")),
