@@ -101,6 +101,13 @@ int ps_bucket_build(const int64_t *rowptr, const int32_t *col, const double *cdf
 int ps_bucket_build_half(const int64_t *rowptr, const int32_t *col, const double *cdf, const int32_t *guide, int64_t V,
                          int64_t E, void *buckets, ps_stream_t stream);
 
+/* Destination records: dest_info[e] = the nodeinfo record (row start, degree) of col[e], 8 bytes per edge, 8-B aligned.  Read
+ * contiguously with a start row (the walk kernels stage it into LDS next to the row's blocks), it tells a walk the row of the
+ * node it has just picked without a gather of its own: step 1 of a walk is then ONE dependent round trip to memory (the bucket
+ * record) instead of two.  Pays where the node records themselves are not cache resident (V * 8 bytes beyond the L2 / MALL:
+ * BASELINE config 5, 110 M nodes); optional. */
+int ps_dest_info_build(const int32_t *col, const uint32_t *nodeinfo, int64_t E, int64_t V, void *dest_info, ps_stream_t stream);
+
 /* flags[0] = 1 iff some edge points at a node with out-degree 0 (a reachable sink: the
  * reference's walk then breaks early, utils/random_walk.py:68-69, and its RNG consumption
  * becomes data dependent); flags[1] = max out-degree.  flags int64[2]. */
@@ -121,13 +128,14 @@ int ps_graph_stats(const int64_t *rowptr, const int32_t *col, int64_t E, int64_t
  * the interleaved 128-byte blocks instead of the three arrays; start rows of up to ~40 blocks are searched in LDS.
  * With packed, col / cdf / guide may be NULL (the blocks hold the same values: graphs that fill the GPU drop the plain arrays).
  * buckets (from ps_bucket_build; needs nodeinfo) answers every other step from one 64-byte record; with PS_WALK_HALF_BUCKETS
- * OR-ed into rng_mode it is the 32-byte form of ps_bucket_build_half. */
+ * OR-ed into rng_mode it is the 32-byte form of ps_bucket_build_half.
+ * dest_info (from ps_dest_info_build; needs packed; may be NULL): the (row start, degree) record of every edge's destination. */
 int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                    const int64_t *starts, int64_t B, int W, int L, int T,
                    int rng_mode, const double *uniforms, const int64_t *uoff,
                    uint64_t seed, uint32_t call, const uint32_t *nodeinfo, const int32_t *guide,
-                   const void *packed, const void *buckets, int32_t *ids, int32_t *counts, int32_t *nvalid,
-                   ps_stream_t stream);
+                   const void *packed, const void *buckets, const void *dest_info,
+                   int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream);
 
 /* PinSage.get_embeddings draws one fresh sample per GCN layer for the SAME start nodes (model/pinsage.py:271-275:
  * `for layer in range(num_layers): batch_sample_neighbors(nodes, num_neighbors)`).  This entry point runs `layers`
@@ -140,7 +148,7 @@ int ps_walk_sample_layers(const int64_t *rowptr, const int32_t *col, const doubl
                           const int64_t *starts, int64_t B, int W, int L, int T,
                           int rng_mode, const double *uniforms, const int64_t *uoff, int64_t layer_stride,
                           uint64_t seed, uint32_t call, const uint32_t *nodeinfo, const int32_t *guide,
-                          const void *packed, const void *buckets, int layers,
+                          const void *packed, const void *buckets, const void *dest_info, int layers,
                           int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream);
 
 /* _single_walk (utils/random_walk.py:52-83), batched: one walk of L steps per start node, one lane

@@ -320,6 +320,29 @@ extern "C" int ps_guide_build(const int64_t *rowptr, const double *cdf, int64_t 
     return PS_OK;
 }
 
+namespace {
+__global__ void dest_info_kernel(const int32_t *__restrict__ col, const uint2 *__restrict__ nodeinfo, int64_t E, int64_t V,
+                                 uint2 *__restrict__ dest) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t d = col[e];
+        dest[e] = (d >= 0 && d < V) ? nodeinfo[d] : make_uint2(0u, 0u);
+    }
+}
+}  // namespace
+
+extern "C" int ps_dest_info_build(const int32_t *col, const uint32_t *nodeinfo, int64_t E, int64_t V, void *dest_info,
+                                  ps_stream_t stream) {
+    if (E < 0 || V < 0) return PS_EINVAL;
+    if (E == 0) return PS_OK;
+    if (!col || !nodeinfo || !dest_info || reinterpret_cast<size_t>(dest_info) % 8 != 0) return PS_EINVAL;
+    int64_t grid = ps_cdiv(E, 256);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(dest_info_kernel, dim3((unsigned)grid), dim3(256), 0, ps_stream(stream), col,
+                       reinterpret_cast<const uint2 *>(nodeinfo), E, V, reinterpret_cast<uint2 *>(dest_info));
+    PS_CHECK_LAUNCH();
+    return PS_OK;
+}
+
 extern "C" int ps_bucket_build(const int64_t *rowptr, const int32_t *col, const double *cdf, const int32_t *guide,
                                int64_t V, int64_t E, void *buckets, ps_stream_t stream) {
     if (V < 0 || E < 0) return PS_EINVAL;

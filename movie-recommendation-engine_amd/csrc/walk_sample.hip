@@ -43,6 +43,7 @@ struct WalkArgs {
     int bitmap_words;               // LDS words of the count-class bitmap: W * L / 32 + 1, padded
     int rounds;                     // independent samples per start node (one per GCN layer), all in one wave
     int64_t round_stride;           // PS_RNG_STREAM: uniforms of round r start at r * round_stride + uoff[i]
+    const uint2 *dest_info;         // per edge e: (row start, degree) of col[e] (ps_dest_info_build) or NULL
 };
 
 // One Philox4x32-10 block = the uniforms of two consecutive steps of a walk: counter (node, walk, step / 2, call);
@@ -181,7 +182,7 @@ struct LdsEdges {
 // had settled measured 6 % slower); after LIN_PROBES entries, or without a guide, it bisects.
 template <class Acc>
 __device__ __forceinline__ void search_two(const Acc &acc, bool aliveA, eidx_t loA, eidx_t hiA, double uA, bool aliveB,
-                                           eidx_t loB, eidx_t hiB, double uB, int32_t &nA, int32_t &nB) {
+                                           eidx_t loB, eidx_t hiB, double uB, int32_t &nA, int32_t &nB, eidx_t &eA, eidx_t &eB) {
     eidx_t lA = loA, hA = loA, lB = loB, hB = loB;
     int nA_ = LIN_PROBES, nB_ = LIN_PROBES;
     if (acc.has_guide()) {
@@ -239,6 +240,14 @@ __device__ __forceinline__ void search_two(const Acc &acc, bool aliveA, eidx_t l
     }
     if (aliveA) { if (lA >= hiA) lA = hiA - 1; if (nA < 0) nA = acc.k(lA); }
     if (aliveB) { if (lB >= hiB) lB = hiB - 1; if (nB < 0) nB = acc.k(lB); }
+    eA = lA;                                             // the chosen edge (every branch above leaves l on it)
+    eB = lB;
+}
+template <class Acc>
+__device__ __forceinline__ void search_two(const Acc &acc, bool aliveA, eidx_t loA, eidx_t hiA, double uA, bool aliveB,
+                                           eidx_t loB, eidx_t hiB, double uB, int32_t &nA, int32_t &nB) {
+    eidx_t eA, eB;
+    search_two(acc, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB, eA, eB);
 }
 
 // The same search through the 64-byte bucket records: record lo + floor(u * deg) holds the five CDF entries starting
@@ -372,7 +381,9 @@ constexpr int BITMAP_WORDS = 40;   // counts <= 1024 -> 33 words, padded (larger
 
 // STREAM: compiled per RNG mode (the Philox variant carries no stream addressing, the stream variant no Philox state:
 // 83-85 VGPRs instead of 90 for both in one kernel, which is what leaves room for the up-front uniform loads below)
-template <int NP, bool STREAM>
+// DEST: compiled with / without the staged destination records (the extra live values take the stream variant from 95 to 101 VGPRs =
+// four waves per SIMD instead of five; launches without dest_info keep the kernel they had)
+template <int NP, bool STREAM, bool DEST = false>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkArgs a) {
     extern __shared__ int32_t smem[];
     const int lane = threadIdx.x & 63;
@@ -417,10 +428,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         // the start row's packed blocks -> LDS (over the hash-table area, which is initialised after the walks)
         const eidx_t b0 = lo0 >> 3, nblk = ((hi0 - 1) >> 3) - b0 + 1;
         const bool staged = a.packed != nullptr && nblk <= (eidx_t)a.stage_blocks;
+        // with dest_info the (row start, degree) records of the row's destinations follow the blocks in LDS: a walk then knows
+        // the row of its step-1 node when step 0 has picked it, and step 1 is ONE dependent gather (the bucket record) instead
+        // of two (node record, then bucket record)
+        const bool have_dest = DEST && staged && a.dest_info != nullptr;
+        const uint2 *ldest = reinterpret_cast<const uint2 *>(hkey + nblk * 32);      // LDS: [hi0 - lo0] records
         if (staged) {
             const uint4 *src = reinterpret_cast<const uint4 *>(a.packed + (size_t)b0 * 128);
             uint4 *dst = reinterpret_cast<uint4 *>(hkey);
             for (int q = lane; q < (int)nblk * 8; q += 64) dst[q] = src[q];
+            if (have_dest) {
+                uint2 *dd = reinterpret_cast<uint2 *>(hkey + nblk * 32);
+                for (eidx_t e = lo0 + lane; e < hi0; e += 64) dd[e - lo0] = a.dest_info[e];
+            }
         }
         const LdsEdges lrow{reinterpret_cast<const unsigned char *>(hkey), b0};
         ps_wave_lds_sync();
@@ -436,6 +456,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             const bool actA = wA < a.W, actB = wB < a.W;
             bool aliveA = actA, aliveB = actB;
             int32_t curA = (int32_t)s, curB = (int32_t)s;
+            eidx_t edA = lo0, edB = lo0;                     // edge taken by step 0 (inside the staged row)
             double uA1 = 2.0, uB1 = 2.0;
             // stream mode, raw words, L = 2 (the reference's default walk): the four words of a walk's two uniforms are one
             // aligned 16-byte load, requested before the walk starts (uoff is a multiple of W * L, so 2 w is even)
@@ -448,7 +469,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             }
             for (int st = 0; st < a.L; ++st) {
                 eidx_t loA = lo0, hiA = hi0, loB = lo0, hiB = hi0;
-                if (st > 0) {
+                if (st == 1 && have_dest) {
+                    if (aliveA) { const uint2 d = ldest[edA - lo0]; loA = d.x; hiA = d.x + d.y; }
+                    if (aliveB) { const uint2 d = ldest[edB - lo0]; loB = d.x; hiB = d.x + d.y; }
+                } else if (st > 0) {
                     if (aliveA) load_row(a.rowptr, a.nodeinfo, curA, loA, hiA);
                     if (aliveB) load_row(a.rowptr, a.nodeinfo, curB, loB, hiB);
                 }
@@ -478,7 +502,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
                 if (PS_WS_DEBUG & 8) { uA = 0.5; uB = 0.25; }
                 if ((PS_WS_DEBUG & 2) && st > 0) { aliveA = false; aliveB = false; }
                 if ((PS_WS_DEBUG & 1) && st == 0) { nA = grow.k(lo0 + (eidx_t)((uint32_t)lane % (uint32_t)(hi0 - lo0))); nB = nA; }
-                else if (staged && st == 0) search_two(lrow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
+                else if (staged && st == 0) search_two(lrow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB, edA, edB);
                 else if (a.buckets && a.half_buckets) search_two_half(a.buckets, grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
                 else if (a.buckets) search_two_buckets(a.buckets, grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
                 else search_two(grow, aliveA, loA, hiA, uA, aliveB, loB, hiB, uB, nA, nB);
@@ -685,7 +709,7 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
                               const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
                               const double *uniforms, const int64_t *uoff, uint64_t seed, uint32_t call,
                               const uint32_t *nodeinfo, const int32_t *guide, const void *packed, const void *buckets,
-                              int rounds, int64_t round_stride, int32_t *ids, int32_t *counts, int32_t *nvalid,
+                              const void *dest_info, int rounds, int64_t round_stride, int32_t *ids, int32_t *counts, int32_t *nvalid,
                               ps_stream_t stream) {
     const int half_buckets = (rng_mode & PS_WALK_HALF_BUCKETS) ? 1 : 0;      // a flag beside the RNG mode: `buckets` is the 32-byte form
     rng_mode &= ~PS_WALK_HALF_BUCKETS;
@@ -700,6 +724,7 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
     if (!packed && (nodeinfo == nullptr) != (guide == nullptr)) return PS_EINVAL;
     if (packed && !nodeinfo) return PS_EINVAL;
     if (buckets && (!nodeinfo || reinterpret_cast<size_t>(buckets) % 64 != 0)) return PS_EINVAL;
+    if (dest_info && (!packed || reinterpret_cast<size_t>(dest_info) % 8 != 0)) return PS_EINVAL;
     const int64_t P = (int64_t)W * L;
     if (P > 4096) return PS_EUNSUPPORTED;                  // 64 positions per lane: registers (vid / slot / cr) and 160 KiB of LDS end here
     int np = 1;
@@ -708,7 +733,7 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
     while ((1 << hs_log2) * 4 < 5 * P) ++hs_log2;      // table >= 1.25 P slots (load factor <= 0.8)
     WalkArgs a{rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff,
                (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0, reinterpret_cast<const unsigned char *>(buckets), half_buckets, 0,
-               rounds, round_stride};
+               rounds, round_stride, reinterpret_cast<const uint2 *>(dest_info)};
     // LDS budget: the kernel holds 24 waves per CU by registers; 160 KB / 24 leaves ~6.6 KB per wave, and whatever
     // the position buffers and the hash table do not need of that lets longer start rows be staged.
     const int hash_words = 3 * (1 << hs_log2);
@@ -718,7 +743,9 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
     if (region_words < hash_words) region_words = hash_words;
     region_words &= ~31;                                    // whole 128-byte blocks
     a.region_words = region_words;
-    a.stage_blocks = packed ? region_words / 32 : 0;
+    // a staged row = its 128-byte blocks (32 words per 8 edges) [+ 8 bytes per edge of destination records]
+    if (np > 4) a.dest_info = nullptr;                      // (the DEST kernels exist for W * L <= 256, the reference's 100 x 2 among them)
+    a.stage_blocks = packed ? region_words / (a.dest_info ? 48 : 32) : 0;
     const size_t lds = (size_t)WAVES_PER_BLOCK * (rounds * np * 64 + region_words + bitmap_words) * sizeof(int32_t);
     if (lds > 160 * 1024) return PS_EUNSUPPORTED;            // (e.g. eight fused layers of 4096 positions each)
     int64_t grid = ps_cdiv(B, WAVES_PER_BLOCK);
@@ -739,7 +766,13 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
                 done.set(dv, 1);                                                                                               \
             }                                                                                                                  \
         }                                                                                                                      \
-        if (rng_mode == PS_RNG_PHILOX)                                                                                         \
+        if (a.dest_info != nullptr && NP_ <= 4) {                                                                              \
+            constexpr int ND = NP_ <= 4 ? NP_ : 4;      /* only these are instantiated with DEST */                                \
+            if (rng_mode == PS_RNG_PHILOX)                                                                                     \
+                hipLaunchKernelGGL((walk_sample_kernel<ND, false, true>), dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); \
+            else                                                                                                               \
+                hipLaunchKernelGGL((walk_sample_kernel<ND, true, true>), dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a);  \
+        } else if (rng_mode == PS_RNG_PHILOX)                                                                                  \
             hipLaunchKernelGGL((walk_sample_kernel<NP_, false>), dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a); \
         else                                                                                                                   \
             hipLaunchKernelGGL((walk_sample_kernel<NP_, true>), dim3((unsigned)grid), dim3(64 * WAVES_PER_BLOCK), lds, st, a);  \
@@ -763,19 +796,19 @@ extern "C" int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const d
                               const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
                               const double *uniforms, const int64_t *uoff, uint64_t seed, uint32_t call,
                               const uint32_t *nodeinfo, const int32_t *guide, const void *packed, const void *buckets,
-                              int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream) {
+                              const void *dest_info, int32_t *ids, int32_t *counts, int32_t *nvalid, ps_stream_t stream) {
     return walk_sample_launch(rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff, seed, call, nodeinfo, guide,
-                              packed, buckets, 1, 0, ids, counts, nvalid, stream);
+                              packed, buckets, dest_info, 1, 0, ids, counts, nvalid, stream);
 }
 
 extern "C" int ps_walk_sample_layers(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                                      const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
                                      const double *uniforms, const int64_t *uoff, int64_t layer_stride, uint64_t seed,
                                      uint32_t call, const uint32_t *nodeinfo, const int32_t *guide, const void *packed,
-                                     const void *buckets, int layers, int32_t *ids, int32_t *counts, int32_t *nvalid,
-                                     ps_stream_t stream) {
+                                     const void *buckets, const void *dest_info, int layers, int32_t *ids, int32_t *counts,
+                                     int32_t *nvalid, ps_stream_t stream) {
     return walk_sample_launch(rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff, seed, call, nodeinfo, guide,
-                              packed, buckets, layers, layer_stride, ids, counts, nvalid, stream);
+                              packed, buckets, dest_info, layers, layer_stride, ids, counts, nvalid, stream);
 }
 
 extern "C" int ps_walk_paths(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,

@@ -12,7 +12,9 @@ from . import native as nv
 
 
 class DeviceGraph:
-    def __init__(self, edge_index, edge_weights=None, device=None, buckets=None):
+    DEST_INFO_MIN_NODES = 8 << 20        # 64 MiB of node records: beyond what the L2s and most of the MALL hold next to the row data
+
+    def __init__(self, edge_index, edge_weights=None, device=None, buckets=None, dest_info=None):
         dev = nv.require_gpu() if device is None else torch.device(device)
         ei = torch.as_tensor(edge_index)
         if ei.dim() != 2 or ei.size(0) != 2:
@@ -82,6 +84,21 @@ class DeviceGraph:
                     self.buckets, self.bucket_bytes = torch.empty(E * 32, dtype=torch.uint8, device=dev), 32
                     nv.call("ps_bucket_build_half", nv.ptr(self.rowptr), nv.ptr(self.col), nv.ptr(self.cdf), nv.ptr(self.guide),
                             nv.i64(V), nv.i64(E), nv.ptr(self.buckets), nv.stream())
+            # destination records (8 bytes per edge, staged into LDS with a start row): a walk's second step without the gather of
+            # its node record.  Built when the node records are NOT cache resident -- the default catalogue's 1.7 MB of them are L2
+            # hits and the records bought nothing there (r03: 0.419 against 0.413 ms, tools/experiments/) -- i.e. for graphs of more
+            # than DEST_INFO_MIN_NODES nodes (BASELINE config 5: 110 M nodes = 880 MB of node records), memory permitting;
+            # dest_info = True / False (or PS_GRAPH_DEST_INFO=1 / 0) force it.
+            self.dest_info = None
+            want = dest_info
+            if want is None and os.environ.get("PS_GRAPH_DEST_INFO") in ("0", "1"):
+                want = os.environ["PS_GRAPH_DEST_INFO"] == "1"
+            if E and want is not False:
+                free = torch.cuda.mem_get_info(dev)[0]
+                if want is True or (V > self.DEST_INFO_MIN_NODES and E * 8 < free // 4):
+                    self.dest_info = torch.empty(2 * E, dtype=torch.int32, device=dev)
+                    nv.call("ps_dest_info_build", nv.ptr(self.col), nv.ptr(self.nodeinfo), nv.i64(E), nv.i64(V),
+                            nv.ptr(self.dest_info), nv.stream())
             flags = torch.zeros(2, dtype=torch.int64, device=dev)
             nv.call("ps_graph_stats", nv.ptr(self.rowptr), nv.ptr(self.col), nv.i64(E), nv.i64(V), nv.ptr(flags),
                                       nv.stream())
@@ -118,7 +135,7 @@ class DeviceGraph:
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in (self.rowptr, self.col, self.cdf, self.nodeinfo, self.guide, self.packed,
-                                                         self.buckets) if t is not None)
+                                                         self.buckets, self.dest_info) if t is not None)
 
 
 class TargetCSR:

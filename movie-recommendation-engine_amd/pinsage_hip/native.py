@@ -33,7 +33,7 @@ class NativeError(RuntimeError):
 # every exported symbol of include/pinsage_hip.h (checked by tests/test_abi.py)
 SYMBOLS = [
     "ps_abi_version", "ps_error_string", "ps_csr_build_workspace_bytes", "ps_csr_build", "ps_cdf_build",
-    "ps_guide_build", "ps_pack_edges", "ps_bucket_build", "ps_bucket_build_half", "ps_graph_stats", "ps_walk_sample", "ps_walk_sample_layers", "ps_walk_paths", "ps_uniform_offsets", "ps_mt19937_window_shift", "ps_mt19937_workspace_bytes", "ps_mt19937_chunk_log2", "ps_mt19937_random_sample", "ps_mt19937_raw_stream",
+    "ps_guide_build", "ps_pack_edges", "ps_bucket_build", "ps_bucket_build_half", "ps_dest_info_build", "ps_graph_stats", "ps_walk_sample", "ps_walk_sample_layers", "ps_walk_paths", "ps_uniform_offsets", "ps_mt19937_window_shift", "ps_mt19937_workspace_bytes", "ps_mt19937_chunk_log2", "ps_mt19937_random_sample", "ps_mt19937_raw_stream",
     "ps_importance_pool", "ps_permute_k", "ps_linear", "ps_lsh_encode", "ps_hamming_topk_workspace_bytes", "ps_hamming_topk",
     "ps_lsh_planes_bytes", "ps_lsh_expand", "ps_hamming_topk_mfma_workspace_bytes", "ps_hamming_topk_mfma", "ps_hamming_topk_mfma_codes",
     "ps_topk_merge", "ps_topk_merge_strided", "ps_dot_topk_workspace_bytes", "ps_dot_topk", "ps_l2_topk_workspace_bytes", "ps_l2_topk", "ps_ivf_topk_workspace_bytes", "ps_ivf_topk", "ps_spmm_csr",

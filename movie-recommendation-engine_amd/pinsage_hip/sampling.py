@@ -188,7 +188,7 @@ def _sink_stream(graph, starts, W, L, uniforms=None):
 
 
 def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, uniforms=None, use_guide=True, use_packed=True, use_buckets=True,
-                stream_nodes=None):
+                stream_nodes=None, use_dest=True):
     """batch_sample_neighbors on the device.  rng='numpy': the global numpy stream (bit-exact with
     the reference; graphs with reachable sinks take the per-walk stream positions of sink_walk_offsets);
     rng='philox': counter-based.
@@ -243,6 +243,7 @@ def walk_sample(graph, nodes, T, W=100, L=2, rng="numpy", seed=0, call=0, unifor
                                    nv.ptr(graph.guide) if use_guide else nv.ptr(None),
                                    nv.ptr(graph.packed) if (use_guide and use_packed) else nv.ptr(None),
                                    nv.ptr(getattr(graph, "buckets", None)) if (use_guide and use_buckets) else nv.ptr(None),
+                                   nv.ptr(getattr(graph, "dest_info", None)) if (use_guide and use_packed and use_dest) else nv.ptr(None),
                                    nv.ptr(ids), nv.ptr(counts), nv.ptr(nvalid), nv.stream())
     return NeighborBatch(ids, counts, nvalid)
 
@@ -332,7 +333,8 @@ def walk_sample_layers(graph, nodes, T, layers, W=100, L=2, rng="numpy", seed=0,
             nv.call("ps_walk_sample_layers", nv.ptr(graph.rowptr), nv.ptr(graph.col), nv.ptr(graph.cdf), nv.i64(graph.V),
                     nv.ptr(starts), nv.i64(B), nv.i32(W), nv.i32(L), nv.i32(T), nv.i32(mode | graph.walk_flags), nv.ptr(u), nv.ptr(uoff),
                     nv.i64(stride), nv.u64(seed & (2 ** 64 - 1)), nv.u32(call + r0), nv.ptr(graph.nodeinfo), nv.ptr(graph.guide),
-                    nv.ptr(graph.packed), nv.ptr(getattr(graph, "buckets", None)), nv.i32(n), nv.ptr(ids[r0:r0 + n]),
+                    nv.ptr(graph.packed), nv.ptr(getattr(graph, "buckets", None)), nv.ptr(getattr(graph, "dest_info", None)),
+                    nv.i32(n), nv.ptr(ids[r0:r0 + n]),
                     nv.ptr(counts[r0:r0 + n]), nv.ptr(nvalid[r0:r0 + n]), nv.stream())
     return [NeighborBatch(ids[r], counts[r], nvalid[r]) for r in range(layers)]
 

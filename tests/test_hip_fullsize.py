@@ -316,8 +316,8 @@ def test_config5_shaped_graph_without_bucket_records():
     # the 32-byte half records config 5 itself uses (64 GB at 2 x 10^9 edges): same rows again, one launch and fused layers
     del gb
     torch.cuda.empty_cache()
-    gh = DeviceGraph(ei, ew, buckets="half")
-    assert gh.bucket_bytes == 32
+    gh = DeviceGraph(ei, ew, buckets="half", dest_info=True)  # + the destination records config 5's 110 M nodes switch on by themselves
+    assert gh.bucket_bytes == 32 and gh.dest_info is not None and gh.dest_info.numel() == 2 * gh.E
     h = sampling.walk_sample(gh, nodes, 10, 100, 2, rng="philox", seed=42, call=0)
     h2 = sampling.walk_sample_layers(gh, nodes, 10, 2, 100, 2, rng="philox", seed=42, call=0)
     assert torch.equal(a.ids, h.ids) and torch.equal(a.counts, h.counts) and torch.equal(a.nvalid, h.nvalid)
@@ -432,6 +432,7 @@ def test_config5_full_scale_shard_sampling_and_oracle_parity():
     print(f"config 5 graph: V={g.V} E={g.E} max degree {g.max_degree}, {g.nbytes() / 1e9:.1f} GB resident "
           f"({g.bucket_bytes}-byte bucket records), built in {time.time() - t0:.1f} s", flush=True)
     assert g.V == M + U and g.E == 2 * R and g.bucket_bytes == 32 and not g.has_reachable_sink
+    assert g.dest_info is not None                         # 880 MB of node records are not cache resident: destination records on (16 GB)
     deg = g.rowptr[1:] - g.rowptr[:-1]
     assert int(deg[:M].min()) >= 1 and g.max_degree == int(deg.max()) > 1_000_000
     chunk = M // P

@@ -435,6 +435,48 @@ def test_half_bucket_records_match_their_definition_and_the_full_records():
             assert torch.equal(x.ids, y.ids) and torch.equal(x.counts, y.counts)
 
 
+def test_destination_records_match_their_definition_and_change_no_walk():
+    """ps_dest_info_build: dest_info[e] = nodeinfo[col[e]] = (row start, degree) of the edge's destination.  Walks that take the
+    second step's row from these records (staged into LDS with the start row) == walks that gather the node record, in both RNG
+    modes, single and fused layers, with full / half / no bucket records, L = 1 / 2 / 3, start rows too long to stage (hubs) and
+    graphs with sinks (a destination of degree 0 ends the walk)."""
+    from pinsage_hip import sampling
+    from pinsage_hip.graph import DeviceGraph
+    rs = np.random.RandomState(21)
+    ei, ew = bipartite_graph(700, 300, 50000, 5, "half")
+    hub = np.stack([np.full(900, 3), 700 + rs.randint(0, 300, size=900)])                # item-side ids start at 700: a 900+-edge row
+    ei2 = np.concatenate([ei, hub, hub[::-1]], axis=1)
+    ew2 = np.concatenate([ew, np.ones(1800, dtype=np.float32)])
+    sink = np.concatenate([ei, np.stack([rs.randint(0, 700, size=300), 1000 + rs.randint(0, 40, size=300)])], axis=1)   # 40 sink nodes
+    sw = np.concatenate([ew, np.ones(300, dtype=np.float32)])
+    for (e, w, name) in ((ei2, ew2, "hub"), (sink, sw, "sink")):
+        for form in ("half", "full", False):
+            g0 = DeviceGraph(torch.from_numpy(e), torch.from_numpy(w), buckets=form, dest_info=False)
+            g1 = DeviceGraph(torch.from_numpy(e), torch.from_numpy(w), buckets=form, dest_info=True)
+            assert g0.dest_info is None and g1.dest_info is not None
+            ni = g1.nodeinfo.cpu().numpy().reshape(-1, 2)
+            assert np.array_equal(g1.dest_info.cpu().numpy().reshape(-1, 2), ni[g1.col.cpu().numpy()])
+            assert g1.has_reachable_sink == (name == "sink")
+            nodes = np.arange(g1.V)
+            for rng in ("philox", "numpy"):
+                for (W, L, T) in ((100, 2, 10), (64, 1, 5), (40, 3, 8)):
+                    np.random.seed(3)
+                    a = sampling.walk_sample(g0, nodes, T, W, L, rng=rng, seed=9, call=2)
+                    sa = np.random.get_state()[1].copy()
+                    np.random.seed(3)
+                    b = sampling.walk_sample(g1, nodes, T, W, L, rng=rng, seed=9, call=2)
+                    assert np.array_equal(sa, np.random.get_state()[1])
+                    assert torch.equal(a.ids, b.ids) and torch.equal(a.counts, b.counts) and torch.equal(a.nvalid, b.nvalid), (name, form, rng, W, L)
+            if name == "hub":
+                for rng in ("philox", "numpy"):
+                    np.random.seed(4)
+                    two0 = sampling.walk_sample_layers(g0, range(700), 10, 3, 100, 2, rng=rng, seed=4, call=0)
+                    np.random.seed(4)
+                    two1 = sampling.walk_sample_layers(g1, range(700), 10, 3, 100, 2, rng=rng, seed=4, call=0)
+                    for x, y in zip(two0, two1):
+                        assert torch.equal(x.ids, y.ids) and torch.equal(x.counts, y.counts) and torch.equal(x.nvalid, y.nvalid)
+
+
 def test_integration_md_ctypes_stub_reproduces_the_golden(golden):
     """The reference-side ctypes stub printed in INTEGRATION.md (plain C ABI, no accelerator tables) is executed as
     written and must return the reference's neighbours for a golden case."""
