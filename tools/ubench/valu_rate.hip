@@ -22,6 +22,13 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint64_t *stamps, int it
             if (OP == 1) { asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "v"(x)); }
             if (OP == 2) { asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "v"(x)); }
             if (OP == 3) { asm volatile("v_xor_b32 %0, %1, %0\n\tv_bcnt_u32_b32 %0, %0, %1" : "+v"(a[i]) : "v"(x)); }
+            if (OP == 4) { asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(a[i]) : "v"(x)); }
+            if (OP == 5) { asm volatile("v_mul_hi_u32 %0, %1, %0" : "+v"(a[i]) : "v"(x)); }
+            if (OP == 6) {                                   // full 32 x 32 -> 64 product + 64-bit addend in ONE instruction (Philox rounds)
+                uint64_t w = ((uint64_t)a[i] << 32) | a[(i + 1) & 7];
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w) : "v"(x), "v"(a[i]) : "vcc");
+                a[i] = (uint32_t)(w >> 32) ^ (uint32_t)w;
+            }
         }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -74,6 +81,11 @@ void run(const char *name, int nops, int waves_per_simd) {
 }
 
 int main() {
+    for (int w : {1, 4}) {                                   // integer multiplies (the walk sampler's Philox rounds)
+        run<4>("v_mul_lo_u32", 1, w);
+        run<5>("v_mul_hi_u32", 1, w);
+        run<6>("v_mad_u64_u32 (+3 moves)", 1, w);
+    }
     for (int w : {1, 2, 4, 8}) {
         run<0>("v_bcnt_u32_b32", 1, w);
         run<1>("v_xor_b32", 1, w);
