@@ -1135,7 +1135,9 @@ int launch_shard(const GemmArgs &g, hipStream_t st) {
 // image-order weights): the layer GEMM (K = 256 + 256, fused norm) 30.3 -> 26.9 us with the ring of three at 231 tiles and
 // 48.2 -> 45.8 us with the ring of two at 462, the output projection (K = 256, fused norm) 18.3 -> 17.1 / 26.4 -> 26.0; launches
 // WITHOUT the whole-row epilogue are no faster than the 64 x 128 tiles they already use (input projection 11.3 vs 11.1 us,
-// LSH projection 23.4 vs 23.3 at 7 381 rows and 39.9 vs 46.6 at 14 762) and stay there.
+// LSH projection 23.4 vs 23.3 at 7 381 rows and 39.9 vs 46.6 at 14 762) and stay there.  The same ring with 64 x 256 tiles for
+// launches of MANY rows measured 4-13 % SLOWER than the register-staged kernels (59 047 rows: layer GEMM 104.5 -> 100.0 TFLOP/s,
+// LSH projection 111.4 -> 96.7; tools/experiments/r04_gemm_dma_ring_64row_tiles.patch): two workgroups per CU already hide the staging.
 constexpr int64_t SHARD_TILES_RING3 = 256, SHARD_TILES_RING2 = 512;
 
 template <int EPI>
