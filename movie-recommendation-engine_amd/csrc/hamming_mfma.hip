@@ -31,6 +31,8 @@
 //   merge   : every slice leaves one sorted k-list per query (the two lanes of a query merge theirs in LDS);
 //             slice_merge_kernel merges them by (distance, row): 16 lanes per query, k rounds of a DPP row minimum
 //             (slice_merge64_kernel, one wave per query, when few queries over a large table are cut into 17..64 slices).
+// Queries arrive as sign planes (ps_hamming_topk_mfma) or as packed codes (ps_hamming_topk_mfma_codes: the pipelined kernels'
+// workgroups expand their own 32 queries in registers, query_frag; for the older kernels the launcher expands into the workspace).
 // Two generations of sweep kernels live here:
 //   hamming_pipe_kernel<KS, MODE>   (r04; 256- and 512-bit codes, k <= 12: the BASELINE configurations) -- two workgroups per CU,
 //       a ring of single tiles, two accumulator sets per wave: the detection of tile t - 1 runs in the gaps of the MFMA chain of

@@ -4,8 +4,9 @@
 // (reference utils/random_walk.py:52-142).  One 64-lane wave owns one start node:
 //   1. walk phase   : lanes = walks (two per lane); each step is searchsorted(cdf[row], u, 'right') on the
 //                     fp64 per-row CDF (the arithmetic np.random.choice(p=...) performs, :76-79) -- in LDS for
-//                     the start row all walks share (step 0), from one 64-byte bucket record otherwise, through
-//                     the packed blocks / plain arrays as fallbacks (all bit-identical);
+//                     the start row all walks share (step 0), from one 64- or 32-byte bucket record otherwise, through
+//                     the packed blocks / plain arrays as fallbacks (all bit-identical); with destination records
+//                     (ps_dest_info_build) the row of a walk's second node comes out of LDS with the first pick;
 //                     visited ids are staged in LDS in Counter-insertion order (walk-major).
 //   2. count phase  : an LDS open-addressing table keyed by node id gives every position its
 //                     visit count (ds atomics) and first-visit position (atomic min).
