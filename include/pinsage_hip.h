@@ -140,7 +140,8 @@ int ps_walk_sample(const int64_t *rowptr, const int32_t *col, const double *cdf,
 /* PinSage.get_embeddings draws one fresh sample per GCN layer for the SAME start nodes (model/pinsage.py:271-275:
  * `for layer in range(num_layers): batch_sample_neighbors(nodes, num_neighbors)`).  This entry point runs `layers`
  * consecutive samples of every start node in one wave: the start row is brought into LDS once and the per-node fixed
- * chain (start id -> row bounds -> row) is paid once.  Results are exactly those of `layers` ps_walk_sample calls:
+ * chain (start id -> row bounds -> row) is paid once (few start nodes -- a rank's shard -- get one wave per (node, layer)
+ * instead: shorter waves fill the last generation of resident waves better).  Results are exactly those of `layers` ps_walk_sample calls:
  * PS_RNG_PHILOX uses call, call + 1, ...; PS_RNG_STREAM reads layer r's uniforms at r * layer_stride + uoff[i] + w*L + s
  * (layer_stride = the uniforms one whole batch consumes = total[0] of ps_uniform_offsets, i.e. the reference's order:
  * all of layer 0's draws, then all of layer 1's).  ids/counts int32[layers, B, T], nvalid int32[layers, B]. */

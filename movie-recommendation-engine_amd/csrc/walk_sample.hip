@@ -45,6 +45,7 @@ struct WalkArgs {
     int rounds;                     // independent samples per start node (one per GCN layer), all in one wave
     int64_t round_stride;           // PS_RNG_STREAM: uniforms of round r start at r * round_stride + uoff[i]
     const uint2 *dest_info;         // per edge e: (row start, degree) of col[e] (ps_dest_info_build) or NULL
+    int split;                      // 1: a wave walks ONE round of a start node (wave index = round * B + node) instead of all of them
 };
 
 // One Philox4x32-10 block = the uniforms of two consecutive steps of a walk: counter (node, walk, step / 2, call);
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
     const int wv = threadIdx.x >> 6;
     const int HS = 1 << a.hs_log2;
     const int P = a.W * a.L;
-    const int R = a.rounds;
+    const int R = a.split ? 1 : a.rounds;                  // rounds walked by one wave
     const int per_wave = R * NP * 64 + a.region_words + a.bitmap_words;
     int32_t *posb_all = smem + wv * per_wave;               // visited ids of every round, [round][walk * L + step]
     int32_t *hkey = posb_all + R * NP * 64;
@@ -402,7 +403,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
     const int nbw = (P >> 5) + 1;
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
 
-    for (int64_t i = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv; i < a.B; i += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+    const int64_t nwork = a.split ? a.B * a.rounds : a.B;
+    for (int64_t wi = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv; wi < nwork; wi += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const int64_t i = a.split ? wi % a.B : wi;
+        const int rd0 = a.split ? (int)(wi / a.B) : 0;      // first round of this wave
         const int64_t s = uniform_i64(a.starts[i]);
         eidx_t lo0 = 0, hi0 = 0;
         if (s >= 0 && s < a.V) {
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
             hi0 = (eidx_t)uniform_i64(a.rowptr[s + 1]);
         }
         if (hi0 == lo0) {   // isolated start node -> ([], [])  (random_walk.py:109-110)
-            for (int r = 0; r < R; ++r) {
+            for (int r = rd0; r < rd0 + R; ++r) {
                 for (int t = lane; t < a.T; t += 64) { a.ids[(r * a.B + i) * a.T + t] = -1; a.counts[(r * a.B + i) * a.T + t] = 0; }
                 if (lane == 0) a.nvalid[r * a.B + i] = 0;
             }
@@ -450,8 +454,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         // every iteration of the search loop keeps two loads in flight per lane.
         for (int rd = 0; rd < R; ++rd) {
         int32_t *posb = posb_all + rd * NP * 64;
-        const int64_t ubase = ubase0 + rd * a.round_stride;
-        const uint32_t call = a.call + (uint32_t)rd;
+        const int64_t ubase = ubase0 + (rd0 + rd) * a.round_stride;
+        const uint32_t call = a.call + (uint32_t)(rd0 + rd);
         for (int w0 = 0; w0 < a.W; w0 += 128) {
             const int wA = w0 + lane, wB = w0 + 64 + lane;
             const bool actA = wA < a.W, actB = wB < a.W;
@@ -518,8 +522,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         PS_WS_STAMP(6);
         for (int rd = 0; rd < ((PS_WS_DEBUG & 4) ? 0 : R); ++rd) {
         const int32_t *posb = posb_all + rd * NP * 64;
-        int32_t *oid = a.ids + ((int64_t)rd * a.B + i) * a.T;
-        int32_t *ocn = a.counts + ((int64_t)rd * a.B + i) * a.T;
+        int32_t *oid = a.ids + ((int64_t)(rd0 + rd) * a.B + i) * a.T;
+        int32_t *ocn = a.counts + ((int64_t)(rd0 + rd) * a.B + i) * a.T;
         // ---------------- count phase -------------------------------------------------
         for (int h = lane; h < HS; h += 64) { hkey[h] = -1; hcnt[h] = 0; hfirst[h] = 0x7fffffff; }
         for (int b = lane; b < nbw; b += 64) bitmap[b] = 0u;
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void walk_sample_kernel(WalkA
         }
         const int nv = emitted < a.T ? emitted : a.T;
         for (int t = nv + lane; t < a.T; t += 64) { oid[t] = -1; ocn[t] = 0; }
-        if (lane == 0) a.nvalid[(int64_t)rd * a.B + i] = nv;
+        if (lane == 0) a.nvalid[(int64_t)(rd0 + rd) * a.B + i] = nv;
         ps_wave_lds_sync();
         PS_WS_STAMP(8 + rd * 2);
         }
@@ -706,6 +710,10 @@ __global__ void graph_stats_kernel(const int64_t *rowptr, const int32_t *col, in
 
 }  // namespace
 
+// two-layer launches on SYN-25M, tools/ws_split_probe.py (us, one wave per node / per (node, layer)): 3 000 nodes 43.2 / 36.7, 7 381 69.2 / 59.1,
+// 14 762 112.7 / 105.4, 29 524 200.3 / 208.2, 59 047 371.5 / 406.5
+constexpr int64_t SPLIT_MAX_WAVES = 32768;
+
 static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const double *cdf, int64_t V,
                               const int64_t *starts, int64_t B, int W, int L, int T, int rng_mode,
                               const double *uniforms, const int64_t *uoff, uint64_t seed, uint32_t call,
@@ -734,22 +742,31 @@ static int walk_sample_launch(const int64_t *rowptr, const int32_t *col, const d
     while ((1 << hs_log2) * 4 < 5 * P) ++hs_log2;      // table >= 1.25 P slots (load factor <= 0.8)
     WalkArgs a{rowptr, col, cdf, V, starts, B, W, L, T, rng_mode, uniforms, uoff,
                (uint32_t)seed, (uint32_t)(seed >> 32), call, nodeinfo, guide, reinterpret_cast<const unsigned char *>(packed), ids, counts, nvalid, hs_log2, 0, 0, reinterpret_cast<const unsigned char *>(buckets), half_buckets, 0,
-               rounds, round_stride, reinterpret_cast<const uint2 *>(dest_info)};
+               rounds, round_stride, reinterpret_cast<const uint2 *>(dest_info), 0};
+    // Few start nodes (a rank's shard of a multi-GPU job): one wave per (node, round) instead of one per node -- the launch is a
+    // handful of generations of resident waves (256 CUs x 20), and waves of half the life waste half as much in the last one
+    // (7 381 nodes x 2 layers: measured below); many nodes: all rounds of a node in one wave (the start row is staged once: 4 %).
+    // PS_WALK_SPLIT=0 / 1 forces a form (tests run both).
+    {
+        const char *e = getenv("PS_WALK_SPLIT");
+        a.split = rounds > 1 && (e ? atoi(e) != 0 : B * rounds <= SPLIT_MAX_WAVES);
+    }
+    const int wave_rounds = a.split ? 1 : rounds;
     // LDS budget: the kernel holds 24 waves per CU by registers; 160 KB / 24 leaves ~6.6 KB per wave, and whatever
     // the position buffers and the hash table do not need of that lets longer start rows be staged.
     const int hash_words = 3 * (1 << hs_log2);
     const int bitmap_words = P <= 1024 ? BITMAP_WORDS : (int)(((P >> 5) + 1 + 7) & ~7);
     a.bitmap_words = bitmap_words;
-    int region_words = (6656 / 4) - rounds * np * 64 - bitmap_words;
+    int region_words = (6656 / 4) - wave_rounds * np * 64 - bitmap_words;
     if (region_words < hash_words) region_words = hash_words;
     region_words &= ~31;                                    // whole 128-byte blocks
     a.region_words = region_words;
     // a staged row = its 128-byte blocks (32 words per 8 edges) [+ 8 bytes per edge of destination records]
     if (np > 4) a.dest_info = nullptr;                      // (the DEST kernels exist for W * L <= 256, the reference's 100 x 2 among them)
     a.stage_blocks = packed ? region_words / (a.dest_info ? 48 : 32) : 0;
-    const size_t lds = (size_t)WAVES_PER_BLOCK * (rounds * np * 64 + region_words + bitmap_words) * sizeof(int32_t);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * (wave_rounds * np * 64 + region_words + bitmap_words) * sizeof(int32_t);
     if (lds > 160 * 1024) return PS_EUNSUPPORTED;            // (e.g. eight fused layers of 4096 positions each)
-    int64_t grid = ps_cdiv(B, WAVES_PER_BLOCK);
+    int64_t grid = ps_cdiv(a.split ? B * rounds : B, WAVES_PER_BLOCK);
     if (grid > (int64_t)1 << 30) grid = (int64_t)1 << 30;
     hipStream_t st = ps_stream(stream);
     // dynamic LDS beyond 64 KiB (W * L > 1024 only) has to be allowed per kernel and device, once

@@ -505,8 +505,8 @@ def test_integration_md_ctypes_stub_reproduces_the_golden(golden):
 
 @pytest.mark.parametrize("W,L,T,layers", [(100, 2, 10, 2), (100, 2, 50, 3), (10, 3, 5, 2), (130, 1, 7, 4), (20, 2, 5, 11)])   # 11 layers: two launches
 def test_fused_layer_sampling_equals_separate_calls(W, L, T, layers, monkeypatch):
-    """ps_walk_sample_layers (all GCN layers' samples of a node in one wave; model/pinsage.py:271-275 draws them as
-    consecutive batch_sample_neighbors calls) vs `layers` separate launches, in both RNG modes: ids, counts, nvalid
+    """ps_walk_sample_layers (all GCN layers' samples of a node in one wave, or -- few start nodes -- one wave per (node, layer);
+    model/pinsage.py:271-275 draws them as consecutive batch_sample_neighbors calls) vs `layers` separate launches, in both RNG modes: ids, counts, nvalid
     bit-identical, and in numpy mode the same final np.random state.  Isolated start nodes included.
     PS_MT_POISON=1: the item shard's ranged stream buffer is filled with 0xFFFFFFFF before the generator writes its runs, so
     a walk-kernel read outside the rank's runs cannot pass on stale same-seed words left in the allocator's block."""
@@ -525,6 +525,8 @@ def test_fused_layer_sampling_equals_separate_calls(W, L, T, layers, monkeypatch
         sep = [a.sample_batch(torch.arange(M, device=a.graph.device), T) for _ in range(layers)]
         tail = np.random.random_sample()
         for trial in range(2):                                   # the second pass answers the stream total from the cache
+            # both forms of the launch: one wave per (node, layer) -- what few start nodes get by default -- and one wave per node
+            monkeypatch.setenv("PS_WALK_SPLIT", str(trial))
             c = RandomWalkSampler.from_graph(a.graph, walk_length=L, num_walks=W, rng=rng, seed=9)
             np.random.seed(123)
             fused = c.sample_batches(range(M), T, layers)
@@ -533,6 +535,7 @@ def test_fused_layer_sampling_equals_separate_calls(W, L, T, layers, monkeypatch
             for f, s in zip(fused, sep):
                 assert torch.equal(f.ids, s.ids) and torch.equal(f.counts, s.counts) and torch.equal(f.nvalid, s.nvalid)
             assert int((fused[0].nvalid == 0).sum()) == 3
+        monkeypatch.delenv("PS_WALK_SPLIT")
         # tensor start nodes (not a range) and an item shard of the catalogue
         np.random.seed(123)
         fused = b.sample_batches(torch.arange(M), T, layers)
