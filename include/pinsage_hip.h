@@ -241,8 +241,8 @@ int ps_hamming_topk(const uint8_t *qcodes, int64_t nq, const uint8_t *codes, int
  * Replaces the same reference lines as ps_hamming_topk (utils/nearest_neighbors.py:47-68 -> faiss hammings_knn_hc)
  * and returns bit-identical (dist, ids).
  *   ps_lsh_planes_bytes(n, cs)      : size of the plane table of n codes = 4 x the packed codes (0 if cs % 8 != 0)
- *   ps_lsh_expand(codes, n, cs, pl) : builds it (16-B aligned); done at LSHIndex.build time for the table, per call
- *                                     for the queries
+ *   ps_lsh_expand(codes, n, cs, pl) : builds it (16-B aligned); done at LSHIndex.build time for the table (and per call for
+ *                                     the queries by callers of ps_hamming_topk_mfma)
  *   ps_hamming_topk_mfma_codes      : the same search with the QUERIES given as packed codes (4-B aligned, cs bytes each):
  *                                     every workgroup of the scan expands its own 32 queries in registers, which saves
  *                                     the ps_lsh_expand launch in front of a search (the table's planes are still built
