@@ -1,3 +1,5 @@
+#!/bin/bash
+# kernel timeline of ONE per-rank step at P = 8 (tools/shard_sim.py --worlds 8 under rocprofv3 --kernel-trace): bash tools/p8_trace.sh  (through gpurun)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_p8 -o p -- python tools/shard_sim.py --worlds 8 > gpurun_out/p8.log 2>&1
 python - <<PY
