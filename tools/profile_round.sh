@@ -13,6 +13,7 @@ mkdir -p $OUT
 run_trace() {   # tag, bench args...
   tag=$1; shift
   mkdir -p $OUT/$tag
+  # the plain run carries cpu_baseline + parity_check (the whole catalogue through the C oracle, ~3 s); the profiled run does not
   python bench.py --steps 20 --warmup 3 "$@" > $OUT/$tag/bench.json 2> $OUT/$tag/bench.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag/raw -o t -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/$tag/bench_under_rocprof.json 2> $OUT/$tag/rocprof.err
   cp $OUT/$tag/raw/t_kernel_stats.csv $OUT/$tag/kernel_stats.csv
@@ -20,9 +21,9 @@ run_trace() {   # tag, bench args...
   echo "== $tag"; python tools/show_bench.py $OUT/$tag/bench.json | head -12
 }
 run_trace default
-run_trace default_philox --rng philox --no-cpu-baseline
-run_trace config2 --config 2 --no-cpu-baseline
-run_trace config3 --config 3 --no-cpu-baseline
+run_trace default_philox --rng philox
+run_trace config2 --config 2
+run_trace config3 --config 3
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/default/pmc_$c -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/default/pmc_$c.err
 done
