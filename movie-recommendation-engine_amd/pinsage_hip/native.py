@@ -20,6 +20,7 @@ PS_WALK_HALF_BUCKETS = 0x100
 PS_RELU = 1
 PS_L2NORM = 2
 PS_WPERM = 4
+PS_OK, PS_EINVAL, PS_ELAUNCH, PS_EWORKSPACE, PS_EUNSUPPORTED = 0, -1, -2, -3, -4      # status codes (include/pinsage_hip.h)
 
 
 class LibraryMissing(RuntimeError):

@@ -313,6 +313,22 @@ def test_error_paths_raise_loudly():
         idx.search(torch.randn(2, 15), 3)                           # wrong dimensionality
     d, i = idx.search(torch.randn(2, 16), 100)                      # k > 64 and > ntotal: served (exact path), padded like faiss
     assert d.shape == (2, 100) and np.all(i[:, 10:] == -1) and np.all(i[:, :10] >= 0)
+    # C-ABI argument checks of the round-4 entry points (status codes, nothing launched)
+    nv = native
+    L = nv.lib()
+    z = torch.zeros(64, dtype=torch.int32, device="cuda")
+    assert L.ps_dest_info_build(nv.ptr(z), nv.ptr(None), nv.i64(8), nv.i64(4), nv.ptr(z), nv.stream()) == nv.PS_EINVAL       # no node records
+    assert L.ps_dest_info_build(nv.ptr(z), nv.ptr(z), nv.i64(-1), nv.i64(4), nv.ptr(z), nv.stream()) == nv.PS_EINVAL
+    assert L.ps_dest_info_build(nv.ptr(z), nv.ptr(z), nv.i64(0), nv.i64(4), nv.ptr(None), nv.stream()) == nv.PS_OK              # no edges: nothing to do
+    q = torch.zeros((64, 64), dtype=torch.uint8, device="cuda")
+    o32, o64 = torch.zeros((64, 4), dtype=torch.int32, device="cuda"), torch.zeros((64, 4), dtype=torch.int64, device="cuda")
+    big = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    assert L.ps_hamming_topk_mfma_codes(nv.ptr(None), nv.i64(64), nv.ptr(big), nv.i64(4096), nv.i32(64), nv.i32(4), nv.i64(0), nv.ptr(o32),
+                                        nv.ptr(o64), nv.ptr(big), nv.C.c_size_t(1 << 20), nv.stream()) == nv.PS_EINVAL            # no queries
+    assert L.ps_hamming_topk_mfma_codes(nv.ptr(q), nv.i64(8), nv.ptr(big), nv.i64(4096), nv.i32(64), nv.i32(4), nv.i64(0), nv.ptr(o32),
+                                        nv.ptr(o64), nv.ptr(big), nv.C.c_size_t(1 << 20), nv.stream()) == nv.PS_EUNSUPPORTED       # fewer than 64 queries
+    assert L.ps_hamming_topk_mfma_codes(nv.ptr(q), nv.i64(64), nv.ptr(big), nv.i64(4096), nv.i32(64), nv.i32(4), nv.i64(0), nv.ptr(o32),
+                                        nv.ptr(o64), nv.ptr(big), nv.C.c_size_t(16), nv.stream()) == nv.PS_EWORKSPACE               # workspace too small
 
 
 def test_hard_negatives_match_reference_semantics():
