@@ -1,7 +1,7 @@
 #!/bin/bash
-# kernel timeline of ONE per-rank step at P = 8 (tools/shard_sim.py --worlds 8 under rocprofv3 --kernel-trace): bash tools/p8_trace.sh  (through gpurun)
+# kernel timeline of ONE per-rank step at P ranks (tools/shard_sim.py --worlds P under rocprofv3 --kernel-trace; default P = 8): bash tools/p8_trace.sh [P]  (through gpurun)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_p8 -o p -- python tools/shard_sim.py --worlds 8 > gpurun_out/p8.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_p8 -o p -- python tools/shard_sim.py --worlds ${1:-8} > gpurun_out/p8.log 2>&1
 python - <<PY
 import csv
 rows=[r for r in csv.DictReader(open("gpurun_out/prof_p8/p_kernel_trace.csv"))]
